@@ -1,0 +1,165 @@
+/* mctsq_hip.h - C ABI of libmctsq_hip.so: the MI355X (gfx950) hot path of MCTS_Q.
+ *
+ * The reference has no FFI; the boundary it replaces is the Python class API of
+ * /root/reference/src/mctsq_config_dqn_per.py (and mctsq_config_dqn.py).  Each entry point below
+ * names the reference lines whose arithmetic it performs.  Conventions:
+ *   - every function returns 0 on success, <0 on error; mctsq_last_error() gives the message
+ *     (thread-local).  No exceptions cross the boundary.
+ *   - the CALLER owns every buffer; pointers named d_* are DEVICE pointers (HBM), others host.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *   - one process per GPU; calls on different streams of one device may overlap only if they
+ *     touch disjoint buffers.
+ *   - no entry point allocates or frees device memory; scratch comes from the `d_ws` workspace
+ *     argument sized by the matching *_workspace_bytes() query.
+ */
+#ifndef MCTSQ_HIP_H
+#define MCTSQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCTSQ_ABI_VERSION 1
+
+/* encoder kinds (dqn_per.py:181-203) */
+enum { MCTSQ_ENC_CONV = 1, MCTSQ_ENC_GRU = 2, MCTSQ_ENC_TRANSFORMER = 3, MCTSQ_ENC_MLP = 4 };
+/* head activation (dqn_per.py:132-143) */
+enum { MCTSQ_ACT_RELU = 0, MCTSQ_ACT_TANH = 1 };
+/* time features appended in-kernel for the non-_per flavour (mctsq_config_dqn.py:550-587) */
+enum { MCTSQ_TF_NONE = 0, MCTSQ_TF_MINUTE = 1, MCTSQ_TF_GAS_HOURS = 2 };
+
+typedef struct {
+    int32_t kind;      /* MCTSQ_ENC_* */
+    int32_t seq_len;   /* S: 25 (price), 10 (process), 3 (gas/EUA) at the shipped config */
+    int32_t data_dim;  /* features per step in the caller's tensor: 1 / 6 / 2 */
+    int32_t time_feat; /* MCTSQ_TF_*: in-kernel [sin,cos] columns appended after data_dim */
+} mctsq_encoder_desc;
+
+/* TripleEncoderDQN shape (dqn_per.py:146-214). embed_dim must be 64, action_dim <= 16,
+ * hidden_units a multiple of 16 and <= 256, hidden_layers in 1..4. */
+typedef struct {
+    mctsq_encoder_desc enc[3]; /* price, process, gas_eua */
+    int32_t embed_dim;
+    int32_t hidden_layers;
+    int32_t hidden_units;
+    int32_t action_dim;
+    int32_t activation;
+    int32_t reserved;
+} mctsq_net_desc;
+
+int mctsq_abi_version(void);
+const char* mctsq_last_error(void);
+
+/* ---- parameter layout ------------------------------------------------------------------
+ * Parameters live in ONE flat fp32 device buffer, tensors in torch named_parameters() order and
+ * native torch layout, each tensor start padded to a multiple of 16 floats (pads stay zero).
+ * Fills offs[i]/sizes[i] (in floats) for tensor i; returns the tensor count (<0 on error) and
+ * the padded total in *total.  Replaces nothing in the reference: it is what lets
+ * DQNModel.policy_net.parameters() (dqn_per.py:383-398) be views into the buffer the kernels,
+ * Adam and the RCCL all-reduce operate on. */
+int mctsq_param_layout(const mctsq_net_desc* net, int64_t* offs, int64_t* sizes, int cap,
+                       int64_t* total);
+
+/* [S,2] fp32 sin/cos columns the non-_per flavour appends (mctsq_config_dqn.py:550-587 with the
+ * defaults its callers use); host-side, for tests and documentation. */
+int mctsq_time_features(int mode, int seq_len, float* out);
+
+/* ---- Q-network forward: TripleEncoderDQN.forward (dqn_per.py:216-236) fused with the leaf
+ * epilogue of MCTSQ._evaluate / _select (mctsq_config_mcts_per.py:291-296, 367-370).
+ *   d_price [B,S0,F0], d_process [B,S1,F1], d_gas [B,S2,F2] fp32, contiguous.
+ *   d_q [B,A] fp32 (required); d_vmax [B] fp32 = max_a Q; d_argmax [B] int32 = greedy action;
+ *   d_prior [B,A] fp32 = softmax(Q) - each of the last three may be NULL.
+ *   d_ws: workspace of mctsq_q_forward_workspace_bytes(net, B) bytes. */
+int64_t mctsq_q_forward_workspace_bytes(const mctsq_net_desc* net, int64_t B);
+int mctsq_q_forward(const mctsq_net_desc* net, const float* d_params, const float* d_price,
+                    const float* d_process, const float* d_gas, int64_t B, float* d_q,
+                    float* d_vmax, int32_t* d_argmax, float* d_prior, void* d_ws, int64_t ws_bytes,
+                    void* stream);
+
+/* Same, and records the caller's hipEvent_t `ev_encoders_done` (may be NULL) on the stream
+ * between the encoder kernels and the head kernel, so bench.py can time the dominant kernel
+ * with HIP events (no reference counterpart: measurement hook). */
+int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const float* d_price,
+                       const float* d_process, const float* d_gas, int64_t B, float* d_q,
+                       float* d_vmax, int32_t* d_argmax, float* d_prior, void* d_ws,
+                       int64_t ws_bytes, void* stream, void* ev_encoders_done);
+
+/* ---- PER-DQN learner step on an already gathered batch: DQNModel.update (dqn_per.py:455-472)
+ * = policy forward (activations kept), target forward + max, TD target and IS-weighted MSE,
+ * full backward into a flat gradient buffer laid out like the parameters.
+ *   d_s* / d_n*: state / next-state windows as for mctsq_q_forward; d_act int32 [B];
+ *   d_rew, d_done, d_isw fp32 [B]; gamma = discount.
+ *   Outputs: d_grad [total] fp32 (overwritten, UNclipped, already divided by B as the mean
+ *   does), d_loss [1] fp32, d_abs_td [B] fp32 (new priorities, dqn_per.py:474),
+ *   d_qsa [B] and d_target [B] fp32 (optional, may be NULL).
+ * loss_scale: multiply the loss gradient (use 1/world for data-parallel sum-all-reduce with a
+ * per-rank B that is 1/world of the global batch... see INTEGRATION.md); normally 1. */
+int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B);
+int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
+                   const float* d_sprice, const float* d_sprocess, const float* d_sgas,
+                   const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                   const int32_t* d_act, const float* d_rew, const float* d_done,
+                   const float* d_isw, float gamma, float loss_scale, int64_t B, float* d_grad,
+                   float* d_loss, float* d_abs_td, float* d_qsa, float* d_target, void* d_ws,
+                   int64_t ws_bytes, void* stream);
+
+/* ---- clip_grad_norm_(max_norm) + Adam.step + Polyak target update (dqn_per.py:471-472,
+ * 510-516) over the flat buffers, n floats each.  step is 1-based.  tau < 0 skips the target
+ * update; tau == 1 is the hard copy of mctsq_config_dqn.py:547.  d_ws: >= 8 KiB scratch.
+ * d_gnorm (optional) receives the pre-clip global L2 norm. */
+int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
+                           float* d_target, int64_t n, int64_t step, float lr, float beta1,
+                           float beta2, float eps, float max_norm, float tau, float* d_gnorm,
+                           void* d_ws, int64_t ws_bytes, void* stream);
+/* Polyak / hard sync alone: target <- tau*policy + (1-tau)*target (dqn_per.py:515-516). */
+int mctsq_polyak(const float* d_params, float* d_target, int64_t n, float tau, void* stream);
+
+/* ---- prioritized replay: PrioritizedReplayBuffer (dqn_per.py:238-321) as a device-resident
+ * ring + 64-ary integer sum-tree.  Logical index 0 is the OLDEST entry (deque(maxlen)).
+ * Priorities are fp64; probability mass m = rint(prio^alpha * 2^shift) as uint64 (deterministic
+ * pow) so tree sums are exact and order-independent.
+ *
+ * The tree is one uint64 device array of mctsq_per_tree_words(capacity) words, caller-zeroed
+ * before first use; d_prio is fp64 [capacity] in PHYSICAL slot order; head = physical slot of
+ * logical index 0; size = live entries. */
+int64_t mctsq_per_tree_words(int64_t capacity);
+int mctsq_per_mass_shift(int64_t capacity);
+/* push K entries (dqn_per.py:265-267): they take physical slots (head+size+i) % capacity, get
+ * priority *d_maxprio (device scalar fp64 holding max over live priorities, default 1.0), and
+ * their state rows are copied from d_rows_* ([K,row] fp32, staged by the caller).  The caller
+ * advances head/size on the host: size' = min(size+K, cap), head' = (head + max(0,size+K-cap)) % cap. */
+int mctsq_per_push(uint64_t* d_tree, double* d_prio, const double* d_maxprio, int64_t capacity,
+                   int64_t head, int64_t size, int64_t K, double alpha, void* stream);
+/* recompute *d_maxprio = max(prio[live]) (1.0 if empty): the O(N) max() of dqn_per.py:265. */
+int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, int64_t size,
+                          double* d_maxprio, void* d_ws, int64_t ws_bytes, void* stream);
+/* sample (dqn_per.py:283-301): d_u fp64 [B] uniforms in [0,1) -> d_idx int64 [B] LOGICAL
+ * indices, d_phys int64 [B] physical slots, d_w fp32 [B] IS weights (N p_i)^-beta / max. */
+int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
+                     int64_t size, const double* d_u, int64_t B, double alpha, double beta,
+                     int64_t* d_idx, int64_t* d_phys, float* d_w, void* d_ws, int64_t ws_bytes,
+                     void* stream);
+/* update_priorities (dqn_per.py:307-314): prio[idx[i]] = p[i] sequentially (last duplicate
+ * wins); d_idx LOGICAL int64 [B], d_newprio fp32 [B].  d_stamp: int32 [capacity] scratch owned by
+ * the buffer, all -1 on entry (the call leaves it all -1 again). */
+int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t capacity,
+                     int64_t head, int64_t size, const int64_t* d_idx, const float* d_newprio,
+                     int64_t B, double alpha, void* stream);
+/* gather the sampled transitions (dqn_per.py:293, 415-452): rows are 96-float padded
+ * [price 25 | process 10x6 | gas 3x2 | pad] records; outputs are the six window tensors the
+ * learner consumes plus actions / rewards / dones. */
+int mctsq_per_gather(const float* d_states, const float* d_next_states, const int32_t* d_actions,
+                     const float* d_rewards, const float* d_dones, const int64_t* d_phys,
+                     int64_t B, float* d_sprice, float* d_sprocess, float* d_sgas, float* d_nprice,
+                     float* d_nprocess, float* d_ngas, int32_t* d_act, float* d_rew, float* d_done,
+                     void* stream);
+int64_t mctsq_per_workspace_bytes(int64_t capacity, int64_t B);
+
+#define MCTSQ_STATE_ROW 96 /* floats per stored state record (91 used) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCTSQ_HIP_H */

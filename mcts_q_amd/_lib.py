@@ -1,0 +1,93 @@
+"""ctypes binding of lib/libmctsq_hip.so.  Fails loudly when the library is missing: there is no
+CPU fallback for the product path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmctsq_hip.so")
+
+
+class MctsqError(RuntimeError):
+    pass
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("seq_len", C.c_int32), ("data_dim", C.c_int32),
+                ("time_feat", C.c_int32)]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("enc", EncoderDesc * 3), ("embed_dim", C.c_int32), ("hidden_layers", C.c_int32),
+                ("hidden_units", C.c_int32), ("action_dim", C.c_int32), ("activation", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+_vp, _i64, _i32, _f32, _f64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double
+_ND = C.POINTER(NetDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/mctsq_hip.h
+SIGNATURES = {
+    "mctsq_abi_version": (_i32, []),
+    "mctsq_last_error": (C.c_char_p, []),
+    "mctsq_param_layout": (_i32, [_ND, _vp, _vp, _i32, _vp]),
+    "mctsq_time_features": (_i32, [_i32, _i32, _vp]),
+    "mctsq_q_forward_workspace_bytes": (_i64, [_ND, _i64]),
+    "mctsq_q_forward": (_i32, [_ND, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mctsq_q_forward_ex": (_i32, [_ND, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "mctsq_dqn_grad_workspace_bytes": (_i64, [_ND, _i64]),
+    "mctsq_dqn_grad": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32,
+                              _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mctsq_clip_adam_polyak": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32,
+                                      _f32, _vp, _vp, _i64, _vp]),
+    "mctsq_polyak": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+    "mctsq_per_tree_words": (_i64, [_i64]),
+    "mctsq_per_mass_shift": (_i32, [_i64]),
+    "mctsq_per_workspace_bytes": (_i64, [_i64, _i64]),
+    "mctsq_per_push": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _vp]),
+    "mctsq_per_refresh_max": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "mctsq_per_sample": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _vp, _vp, _vp, _vp,
+                                _i64, _vp]),
+    "mctsq_per_update": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _f64, _vp]),
+    "mctsq_per_gather": (_i32, [_vp] * 6 + [_i64] + [_vp] * 10),
+}
+
+
+class _Lib:
+    """Lazy loader so that importing the package on a box without the .so gives a clear error at
+    first use, not an obscure one at import time."""
+
+    def __init__(self):
+        self._dll = None
+
+    def _load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise MctsqError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+            dll = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(dll, name)      # AttributeError if the .so lacks a declared symbol
+                fn.restype, fn.argtypes = res, args
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        return getattr(self._load(), name)
+
+    def check(self, rc):
+        if rc < 0:
+            raise MctsqError(self._load().mctsq_last_error().decode() or f"libmctsq_hip error {rc}")
+        return rc
+
+
+lib = _Lib()
+
+
+def ptr(t):
+    """Raw device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

@@ -1,0 +1,203 @@
+// extern "C" surface of libmctsq_hip.so (see include/mctsq_hip.h).  Host-side argument checks
+// live here: every kernel below assumes the shapes validated in this file.
+#include <string.h>
+
+#include "kernels.hpp"
+#include "per.hpp"
+
+using namespace mctsq;
+
+namespace {
+
+// Build the per-slot argument records for the encoders of one forward pass.
+struct FwdPlan {
+    GruFwdArgs gru;
+    int gru_slots[3];
+};
+
+void fill_gru_slot(GruSlot& g, const EncOff& e, const float* params, const float* x, int slot) {
+    memset(&g, 0, sizeof(g));
+    g.x = x;
+    g.wih = params + e.gru.wih; g.whh = params + e.gru.whh;
+    g.bih = params + e.gru.bih; g.bhh = params + e.gru.bhh;
+    g.aw = params + e.gru.aw;   g.ab = params + e.gru.ab;
+    g.lnw = params + e.gru.lnw; g.lnb = params + e.gru.lnb;
+    g.S = e.S; g.Fd = e.Fd; g.F = e.F; g.tf = e.tf; g.out_col = slot * E;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mctsq_abi_version(void) { return MCTSQ_ABI_VERSION; }
+const char* mctsq_last_error(void) { return mctsq::last_error(); }
+
+int mctsq_param_layout(const mctsq_net_desc* net, int64_t* offs, int64_t* sizes, int cap, int64_t* total) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    for (int i = 0; i < L.n_tensors && i < cap; ++i) {
+        if (offs) offs[i] = L.t_off[i];
+        if (sizes) sizes[i] = L.t_size[i];
+    }
+    if (total) *total = L.total;
+    return L.n_tensors;
+}
+
+int mctsq_time_features(int mode, int seq_len, float* out) {
+    MCTSQ_CHECK(mode == MCTSQ_TF_MINUTE || mode == MCTSQ_TF_GAS_HOURS, "bad time feature mode %d", mode);
+    MCTSQ_CHECK(seq_len >= 1 && seq_len <= MAX_SEQ && out, "bad seq_len / out");
+    host_time_features(mode, seq_len, out);
+    return 0;
+}
+
+int64_t mctsq_q_forward_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    if (B < 0) { set_error("negative batch"); return -1; }
+    const int64_t Bp = round_up(B > 0 ? B : 1, TILE);
+    return Bp * FEAT * (int64_t)sizeof(float);
+}
+
+int mctsq_q_forward(const mctsq_net_desc* net, const float* d_params, const float* d_price,
+                    const float* d_process, const float* d_gas, int64_t B, float* d_q, float* d_vmax,
+                    int32_t* d_argmax, float* d_prior, void* d_ws, int64_t ws_bytes, void* stream) {
+    return mctsq_q_forward_ex(net, d_params, d_price, d_process, d_gas, B, d_q, d_vmax, d_argmax, d_prior, d_ws,
+                              ws_bytes, stream, nullptr);
+}
+
+int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const float* d_price,
+                       const float* d_process, const float* d_gas, int64_t B, float* d_q, float* d_vmax,
+                       int32_t* d_argmax, float* d_prior, void* d_ws, int64_t ws_bytes, void* stream,
+                       void* ev_encoders_done) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_params && d_price && d_process && d_gas && d_q, "NULL device pointer");
+    const int64_t Bp = round_up(B, TILE);
+    MCTSQ_CHECK(d_ws && ws_bytes >= Bp * FEAT * (int64_t)sizeof(float), "workspace too small (%lld bytes)",
+                (long long)ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    float* feats = (float*)d_ws;
+    const float* x[3] = {d_price, d_process, d_gas};
+
+    GruFwdArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.B = B; ga.Bp = Bp; ga.feats = feats;
+    for (int s = 0; s < 3; ++s) {
+        const EncOff& e = L.enc[s];
+        if (e.kind == MCTSQ_ENC_GRU) fill_gru_slot(ga.slot[ga.nslots++], e, d_params, x[s], s);
+        else MCTSQ_CHECK(false, "encoder kind %d is not built into this library yet", e.kind);
+    }
+    if (launch_gru_fwd(ga, false, st)) return -1;
+    if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
+
+    HeadArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
+    for (int i = 0; i < L.n_fc; ++i) {
+        ha.w[i] = d_params + L.fc_w[i]; ha.b[i] = d_params + L.fc_b[i];
+        ha.in[i] = L.fc_in[i]; ha.out[i] = L.fc_out[i];
+    }
+    ha.q = d_q; ha.vmax = d_vmax; ha.argmax = d_argmax; ha.prior = d_prior;
+    return launch_head_fwd(ha, st);
+}
+
+// ------------------------------------------------------------------------------- PER
+int64_t mctsq_per_tree_words(int64_t capacity) {
+    PerTree T;
+    if (per_tree_desc(capacity, &T)) return -1;
+    return T.words;
+}
+int mctsq_per_mass_shift(int64_t capacity) { return per_mass_shift(capacity); }
+
+int64_t mctsq_per_workspace_bytes(int64_t capacity, int64_t B) {
+    (void)capacity;
+    const int64_t a = (B > 0 ? B : 1) * 8, b = 1024 * 8;
+    return a > b ? a : b;
+}
+
+static int check_ring(int64_t capacity, int64_t head, int64_t size) {
+    MCTSQ_CHECK(capacity >= 1, "capacity must be >= 1");
+    MCTSQ_CHECK(size >= 0 && size <= capacity, "size %lld outside [0, capacity]", (long long)size);
+    MCTSQ_CHECK(head >= 0 && head < capacity, "head %lld outside [0, capacity)", (long long)head);
+    MCTSQ_CHECK(size == capacity || head == 0, "head must be 0 until the ring is full");
+    return 0;
+}
+
+int mctsq_per_push(uint64_t* d_tree, double* d_prio, const double* d_maxprio, int64_t capacity, int64_t head,
+                   int64_t size, int64_t K, double alpha, void* stream) {
+    if (check_ring(capacity, head, size)) return -1;
+    MCTSQ_CHECK(d_tree && d_prio && d_maxprio, "NULL device pointer");
+    MCTSQ_CHECK(K >= 0 && K <= capacity, "push count %lld outside [0, capacity]", (long long)K);
+    if (K == 0) return 0;
+    return launch_per_push((unsigned long long*)d_tree, d_prio, d_maxprio, capacity, head, size, K, alpha,
+                           (hipStream_t)stream);
+}
+
+int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, int64_t size, double* d_maxprio,
+                          void* d_ws, int64_t ws_bytes, void* stream) {
+    if (check_ring(capacity, head, size)) return -1;
+    MCTSQ_CHECK(d_prio && d_maxprio && d_ws && ws_bytes >= 1024 * 8, "NULL pointer or workspace < 8 KiB");
+    // live entries are physical [0, size) (ring not full) or all of [0, capacity)
+    return launch_per_refresh_max(d_prio, size, d_maxprio, (double*)d_ws, 1024, (hipStream_t)stream);
+}
+
+int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
+                     const double* d_u, int64_t B, double alpha, double beta, int64_t* d_idx, int64_t* d_phys,
+                     float* d_w, void* d_ws, int64_t ws_bytes, void* stream) {
+    if (check_ring(capacity, head, size)) return -1;
+    MCTSQ_CHECK(size >= 1, "cannot sample from an empty buffer");
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_tree && d_prio && d_u && d_idx && d_phys && d_w, "NULL device pointer");
+    MCTSQ_CHECK(d_ws && ws_bytes >= B * 8, "workspace too small");
+    return launch_per_sample((const unsigned long long*)d_tree, d_prio, capacity, head, size, d_u, B, alpha,
+                             beta, d_idx, d_phys, d_w, (double*)d_ws, (hipStream_t)stream);
+}
+
+int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t capacity, int64_t head,
+                     int64_t size, const int64_t* d_idx, const float* d_newprio, int64_t B, double alpha,
+                     void* stream) {
+    if (check_ring(capacity, head, size)) return -1;
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_tree && d_prio && d_stamp && d_idx && d_newprio, "NULL device pointer");
+    MCTSQ_CHECK(B < ((int64_t)1 << 31), "update batch too large");
+    return launch_per_update((unsigned long long*)d_tree, d_prio, d_stamp, capacity, head, d_idx, d_newprio, B, alpha,
+                             (hipStream_t)stream);
+}
+
+int mctsq_per_gather(const float* d_states, const float* d_next_states, const int32_t* d_actions,
+                     const float* d_rewards, const float* d_dones, const int64_t* d_phys, int64_t B,
+                     float* d_sprice, float* d_sprocess, float* d_sgas, float* d_nprice, float* d_nprocess,
+                     float* d_ngas, int32_t* d_act, float* d_rew, float* d_done, void* stream) {
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_states && d_next_states && d_actions && d_rewards && d_dones && d_phys && d_sprice &&
+                    d_sprocess && d_sgas && d_nprice && d_nprocess && d_ngas && d_act && d_rew && d_done,
+                "NULL device pointer");
+    PerGatherArgs a;
+    a.states = d_states; a.next_states = d_next_states; a.actions = d_actions; a.rewards = d_rewards;
+    a.dones = d_dones; a.phys = d_phys; a.B = B;
+    a.sprice = d_sprice; a.sprocess = d_sprocess; a.sgas = d_sgas;
+    a.nprice = d_nprice; a.nprocess = d_nprocess; a.ngas = d_ngas;
+    a.act = d_act; a.rew = d_rew; a.done = d_done;
+    return launch_per_gather(a, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// -------- learner step: placeholder until learner.hip lands (symbols must exist for the ABI) -----
+extern "C" int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
+    (void)net; (void)B;
+    set_error("mctsq_dqn_grad is not built into this library yet");
+    return -1;
+}
+extern "C" int mctsq_dqn_grad(const mctsq_net_desc*, const float*, const float*, const float*, const float*,
+                              const float*, const float*, const float*, const float*, const int32_t*,
+                              const float*, const float*, const float*, float, float, int64_t, float*, float*,
+                              float*, float*, float*, void*, int64_t, void*) {
+    set_error("mctsq_dqn_grad is not built into this library yet");
+    return -1;
+}

@@ -1,0 +1,118 @@
+// Q head forward: fc_layers of TripleEncoderDQN (dqn_per.py:205-214, 235-236) fused with the
+// leaf epilogue the callers apply (mcts_per.py:293 softmax prior, :370 max; argmax for greedy
+// parity).  One workgroup = 16 samples; every Linear is a [16 x K] . [K x N] product on
+// v_mfma_f32_16x16x4_f32 with the activations ping-ponged through LDS and the weight fragments
+// streamed from L2 (the whole head is 164 KB).
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace mctsq {
+
+constexpr int ALD = 260;   // LDS row stride (floats): max width 256 + 4
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jl = lane & 15, q = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * TILE;
+    __shared__ __attribute__((aligned(16))) float buf[2][TILE * ALD];
+
+    for (int idx = tid; idx < TILE * (FEAT / 4); idx += 256) {      // feats tile, float4 copies
+        const int i = idx / (FEAT / 4), c = idx - i * (FEAT / 4);
+        const float4 v = reinterpret_cast<const float4*>(a.feats + (row0 + i) * (int64_t)FEAT)[c];
+        *reinterpret_cast<float4*>(&buf[0][i * ALD + 4 * c]) = v;
+    }
+    __syncthreads();
+
+    for (int l = 0; l < a.n_fc; ++l) {
+        const int K = a.in[l], N = a.out[l], K4 = K >> 2, nt = (N + 15) >> 4;
+        const float* W = a.w[l];
+        const float* src = buf[l & 1];
+        float* dst = buf[(l + 1) & 1];
+        const bool last = l == a.n_fc - 1;
+        const float* xa = src + (lane & 15) * ALD + q * K4;
+        for (int t0 = w; t0 < nt; t0 += 8) {
+            const int jA = t0 * 16 + jl, jB = (t0 + 4) * 16 + jl;
+            const bool hasB = (t0 + 4) < nt;                       // wave-uniform
+            const bool okA = jA < N, okB = hasB && jB < N;
+            const float* wa = W + (int64_t)(okA ? jA : 0) * K + q * K4;
+            const float* wb = W + (int64_t)(okB ? jB : 0) * K + q * K4;
+            f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+            const float4 zero4 = make_float4(0, 0, 0, 0);
+            if (hasB) {
+#pragma unroll 4
+                for (int kk = 0; kk < K4; kk += 4) {
+                    const float4 av = *reinterpret_cast<const float4*>(xa + kk);
+                    const float4 b1 = okA ? *reinterpret_cast<const float4*>(wa + kk) : zero4;
+                    const float4 b2 = okB ? *reinterpret_cast<const float4*>(wb + kk) : zero4;
+                    accA = mfma16(av.x, b1.x, accA); accB = mfma16(av.x, b2.x, accB);
+                    accA = mfma16(av.y, b1.y, accA); accB = mfma16(av.y, b2.y, accB);
+                    accA = mfma16(av.z, b1.z, accA); accB = mfma16(av.z, b2.z, accB);
+                    accA = mfma16(av.w, b1.w, accA); accB = mfma16(av.w, b2.w, accB);
+                }
+            } else {
+#pragma unroll 4
+                for (int kk = 0; kk < K4; kk += 4) {
+                    const float4 av = *reinterpret_cast<const float4*>(xa + kk);
+                    const float4 b1 = okA ? *reinterpret_cast<const float4*>(wa + kk) : zero4;
+                    accA = mfma16_x4(av, b1, accA);
+                }
+            }
+            if (okA) {
+                const float bias = a.b[l][jA];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = accA[r] + bias;
+                    if (!last) v = apply_act(v, a.act);
+                    dst[(4 * q + r) * ALD + jA] = v;
+                    if (SAVE && !last) a.sv_act[l][(row0 + 4 * q + r) * (int64_t)N + jA] = v;
+                }
+            }
+            if (okB) {
+                const float bias = a.b[l][jB];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = accB[r] + bias;
+                    if (!last) v = apply_act(v, a.act);
+                    dst[(4 * q + r) * ALD + jB] = v;
+                    if (SAVE && !last) a.sv_act[l][(row0 + 4 * q + r) * (int64_t)N + jB] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: one lane per sample ------------------------------------------------
+    if (tid < TILE && row0 + tid < a.B) {
+        const float* qv = buf[a.n_fc & 1] + tid * ALD;
+        const int64_t row = row0 + tid;
+        float best = qv[0];
+        int arg = 0;
+        for (int k = 1; k < a.A; ++k)
+            if (qv[k] > best) { best = qv[k]; arg = k; }       // first maximum, like torch.argmax
+        float den = 0.0f;
+        for (int k = 0; k < a.A; ++k) den += expf(qv[k] - best);
+        for (int k = 0; k < a.A; ++k) {
+            a.q[row * a.A + k] = qv[k];
+            if (a.prior) a.prior[row * a.A + k] = expf(qv[k] - best) / den;
+        }
+        if (a.vmax) a.vmax[row] = best;
+        if (a.argmax) a.argmax[row] = arg;
+    }
+}
+
+int launch_head_fwd(const HeadArgs& args, hipStream_t st) {
+    if (args.B == 0) return 0;
+    for (int l = 0; l < args.n_fc; ++l) {
+        MCTSQ_CHECK(args.in[l] % 16 == 0 && args.in[l] <= 256, "head layer %d: K=%d unsupported", l, args.in[l]);
+        MCTSQ_CHECK(args.out[l] <= 256, "head layer %d: N=%d unsupported", l, args.out[l]);
+    }
+    const bool save = args.sv_act[0] != nullptr;
+    dim3 grid((unsigned)(args.Bp / TILE));
+    if (save) hipLaunchKernelGGL(head_fwd_kernel<true>, grid, dim3(256), 0, st, args);
+    else hipLaunchKernelGGL(head_fwd_kernel<false>, grid, dim3(256), 0, st, args);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mctsq

@@ -1,0 +1,40 @@
+// Kernel argument records + launcher prototypes (internal to libmctsq_hip.so).
+#pragma once
+#include "common.hpp"
+
+namespace mctsq {
+
+// ---------------- GRU-attention encoder ----------------
+struct GruSlot {
+    const float* x;                      // [B][S][Fd]
+    const float *wih, *whh, *bih, *bhh, *aw, *ab, *lnw, *lnb;
+    int S, Fd, F, tf, out_col;
+    // training-time activation record (NULL for inference), Bp = padded batch
+    float *sv_h, *sv_r, *sv_z, *sv_n, *sv_hn;   // [S][Bp][64]
+    float* sv_score;                     // [S][Bp]
+    float* sv_stat;                      // [Bp][4] = running max, running sum, LN mean, LN rstd
+    float* sv_pool;                      // [Bp][64] pooled vector before LayerNorm
+};
+struct GruFwdArgs {
+    GruSlot slot[3];
+    int nslots;
+    int64_t B, Bp;
+    float* feats;                        // [Bp][192]
+};
+inline int64_t gru_save_floats(int S, int64_t Bp) { return 5 * (int64_t)S * Bp * E + (int64_t)S * Bp + 4 * Bp + E * Bp; }
+int launch_gru_fwd(const GruFwdArgs& args, bool save, hipStream_t st);
+
+// ---------------- head ----------------
+struct HeadArgs {
+    const float* feats;                  // [Bp][192]
+    const float* w[5];
+    const float* b[5];
+    int n_fc, in[5], out[5], act, A;
+    int64_t B, Bp;
+    float *q, *vmax, *prior;             // [B][A], [B], [B][A]; vmax/prior may be NULL
+    int32_t* argmax;                     // [B] or NULL
+    float* sv_act[4];                    // training: post-activation hidden layers [Bp][H] or NULL
+};
+int launch_head_fwd(const HeadArgs& args, hipStream_t st);
+
+}  // namespace mctsq

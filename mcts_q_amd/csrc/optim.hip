@@ -1,0 +1,132 @@
+// clip_grad_norm_(max_norm) + Adam.step + Polyak target update over flat fp32 buffers
+// (dqn_per.py:471-472 and :510-516; hard copy of mctsq_config_dqn.py:547 when tau == 1).
+// HBM-bound streaming: 5 reads + 4 writes of 4 bytes per parameter, float4-vectorised.
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace mctsq {
+
+constexpr int NPART = 256;     // partial sums of squares (fixed order -> bitwise reproducible norm)
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n,
+                                                            double* __restrict__ part) {
+    __shared__ double red[4];
+    const int64_t n4 = n >> 2;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)NPART * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; float* tgt;
+    int64_t n;
+    float step_size, bc2_sqrt, b1, b2, eps, max_norm, tau;
+    const double* part;
+    float* gnorm_out;
+};
+
+__global__ __launch_bounds__(256) void clip_adam_polyak_kernel(AdamArgs a) {
+    __shared__ float s_coef;
+    if (threadIdx.x < 64) {                       // every block folds the same 256 partials, same order
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < NPART; i += 64) acc += a.part[i];
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (threadIdx.x == 0) {
+            const float total = (float)sqrt(acc);
+            s_coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
+            if (blockIdx.x == 0 && a.gnorm_out) *a.gnorm_out = total;
+        }
+    }
+    __syncthreads();
+    const float coef = s_coef;
+    const int64_t n4 = a.n >> 2;
+    const float one_m_b1 = 1.0f - a.b1, one_m_b2 = 1.0f - a.b2;
+    const float tau = a.tau, one_m_tau = (float)(1.0 - (double)a.tau);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        const float4 g4 = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &g4.x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float g = pg[c] * coef;
+            pm[c] = pm[c] + (g - pm[c]) * one_m_b1;                      // exp_avg.lerp_(g, 1-b1)
+            pv[c] = __fadd_rn(__fmul_rn(pv[c], a.b2), __fmul_rn(__fmul_rn(g, g), one_m_b2));
+            const float denom = sqrtf(pv[c]) / a.bc2_sqrt + a.eps;
+            pp[c] = pp[c] - a.step_size * (pm[c] / denom);
+        }
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (a.tgt) {
+            float4 t = reinterpret_cast<float4*>(a.tgt)[i];
+            float* pt = &t.x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pt[c] = __fadd_rn(__fmul_rn(tau, pp[c]), __fmul_rn(one_m_tau, pt[c]));
+            reinterpret_cast<float4*>(a.tgt)[i] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void polyak_kernel(const float* __restrict__ p, float* __restrict__ tgt,
+                                                     int64_t n4, float tau, float one_m_tau) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 s = reinterpret_cast<const float4*>(p)[i];
+        float4 t = reinterpret_cast<float4*>(tgt)[i];
+        t.x = __fadd_rn(__fmul_rn(tau, s.x), __fmul_rn(one_m_tau, t.x));
+        t.y = __fadd_rn(__fmul_rn(tau, s.y), __fmul_rn(one_m_tau, t.y));
+        t.z = __fadd_rn(__fmul_rn(tau, s.z), __fmul_rn(one_m_tau, t.z));
+        t.w = __fadd_rn(__fmul_rn(tau, s.w), __fmul_rn(one_m_tau, t.w));
+        reinterpret_cast<float4*>(tgt)[i] = t;
+    }
+}
+
+static unsigned stream_grid(int64_t n4) {
+    int64_t g = (n4 + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace mctsq
+
+using namespace mctsq;
+
+extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
+                                      float* d_target, int64_t n, int64_t step, float lr, float beta1,
+                                      float beta2, float eps, float max_norm, float tau, float* d_gnorm,
+                                      void* d_ws, int64_t ws_bytes, void* stream) {
+    MCTSQ_CHECK(d_params && d_grad && d_m && d_v, "NULL device pointer");
+    MCTSQ_CHECK(n > 0 && n % 16 == 0, "flat buffer length must be a positive multiple of 16 (padded layout)");
+    MCTSQ_CHECK(step >= 1, "Adam step is 1-based");
+    MCTSQ_CHECK(d_ws && ws_bytes >= (int64_t)(NPART * sizeof(double)), "workspace must be >= 8 KiB");
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)d_ws;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NPART), dim3(256), 0, st, d_grad, n, part);
+    AdamArgs a;
+    a.p = d_params; a.g = d_grad; a.m = d_m; a.v = d_v; a.tgt = tau >= 0.0f ? d_target : nullptr;
+    a.n = n;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.max_norm = max_norm; a.tau = tau;
+    a.part = part; a.gnorm_out = d_gnorm;
+    MCTSQ_CHECK(tau < 0.0f || d_target, "target buffer is NULL but tau >= 0");
+    hipLaunchKernelGGL(clip_adam_polyak_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mctsq_polyak(const float* d_params, float* d_target, int64_t n, float tau, void* stream) {
+    MCTSQ_CHECK(d_params && d_target, "NULL device pointer");
+    MCTSQ_CHECK(n > 0 && n % 16 == 0, "flat buffer length must be a positive multiple of 16 (padded layout)");
+    hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, d_params,
+                       d_target, n >> 2, tau, (float)(1.0 - (double)tau));
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,128 @@
+"""Device-resident prioritized replay: ring buffer of transitions + 64-ary integer sum-tree.
+
+Host-side mirror of PrioritizedReplayBuffer (/root/reference/src/mctsq_config_dqn_per.py:238-321):
+push (max-priority rule), sample (proportional, with replacement, IS weights), update_priorities
+(sequential semantics: last duplicate wins).  Logical index 0 is the oldest entry, as in
+deque(maxlen).  All arithmetic is in libmctsq_hip.so; see DESIGN.md for the fixed-point mass
+formulation that makes sampled indices bit-identical to the oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ._lib import lib, ptr, MctsqError
+
+ROW = 96          # floats per stored state record (91 used): price 25 | process 10x6 | gas 3x2 | pad
+
+
+class DevicePER:
+    def __init__(self, capacity: int, alpha: float = 0.6, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise MctsqError("DevicePER needs a GPU: the HIP path has no CPU fallback")
+        self.capacity, self.alpha = int(capacity), float(alpha)
+        self.device = torch.device(device)
+        d = self.device
+        self.head, self.size = 0, 0
+        words = lib.check(lib.mctsq_per_tree_words(self.capacity))
+        self.tree = torch.zeros(words, dtype=torch.int64, device=d)       # uint64 bit patterns
+        self.prio = torch.zeros(self.capacity, dtype=torch.float64, device=d)
+        self.maxprio = torch.ones(1, dtype=torch.float64, device=d)
+        self.states = torch.zeros(self.capacity, ROW, dtype=torch.float32, device=d)
+        self.next_states = torch.zeros(self.capacity, ROW, dtype=torch.float32, device=d)
+        self.actions = torch.zeros(self.capacity, dtype=torch.int32, device=d)
+        self.rewards = torch.zeros(self.capacity, dtype=torch.float32, device=d)
+        self.dones = torch.zeros(self.capacity, dtype=torch.float32, device=d)
+        self.stamp = torch.full((self.capacity,), -1, dtype=torch.int32, device=d)
+        self._max_dirty = False
+        self._ws = torch.empty(1 << 16, dtype=torch.uint8, device=d)
+
+    def __len__(self):
+        return self.size
+
+    def _st(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ws_for(self, B):
+        need = lib.check(lib.mctsq_per_workspace_bytes(self.capacity, B))
+        if self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- push -------------------------------------------------------------------------
+    def push_rows(self, rows, actions, rewards, next_rows, dones):
+        """Append K transitions.  rows/next_rows: [K,91] (or [K,96]) fp32; actions int; rewards,
+        dones float.  Every new entry gets the current max priority (dqn_per.py:265-267)."""
+        K = int(rows.shape[0])
+        if K == 0:
+            return
+        if K > self.capacity:
+            raise ValueError("push batch larger than capacity")
+        d = self.device
+        if self._max_dirty:
+            ws = self._ws_for(1)
+            lib.check(lib.mctsq_per_refresh_max(ptr(self.prio), self.capacity, self.head, self.size,
+                                                ptr(self.maxprio), ptr(ws), ws.numel(), self._st()))
+            self._max_dirty = False
+        slots = (torch.arange(K, device=d) + (self.head + self.size)) % self.capacity
+        rows = torch.as_tensor(rows, dtype=torch.float32, device=d)
+        next_rows = torch.as_tensor(next_rows, dtype=torch.float32, device=d)
+        w = rows.shape[1]
+        self.states[slots, :w] = rows
+        self.next_states[slots, :w] = next_rows
+        self.actions[slots] = torch.as_tensor(actions, device=d).to(torch.int32)
+        self.rewards[slots] = torch.as_tensor(rewards, device=d).to(torch.float32)
+        self.dones[slots] = torch.as_tensor(dones, device=d).to(torch.float32)
+        lib.check(lib.mctsq_per_push(ptr(self.tree), ptr(self.prio), ptr(self.maxprio), self.capacity,
+                                     self.head, self.size, K, self.alpha, self._st()))
+        over = max(0, self.size + K - self.capacity)
+        self.size = min(self.size + K, self.capacity)
+        self.head = (self.head + over) % self.capacity
+
+    # ---- sample -----------------------------------------------------------------------
+    def sample_indices(self, u, beta: float = 0.4):
+        """u: fp64 uniforms in [0,1) (host array or device tensor).  Returns device tensors
+        (logical idx int64 [B], physical slot int64 [B], IS weights fp32 [B])."""
+        if self.size == 0:
+            raise ValueError("cannot sample from an empty buffer")
+        u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
+        B = u.numel()
+        idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        phys = torch.empty(B, dtype=torch.int64, device=self.device)
+        w = torch.empty(B, dtype=torch.float32, device=self.device)
+        ws = self._ws_for(B)
+        lib.check(lib.mctsq_per_sample(ptr(self.tree), ptr(self.prio), self.capacity, self.head, self.size,
+                                       ptr(u), B, self.alpha, beta, ptr(idx), ptr(phys), ptr(w), ptr(ws),
+                                       ws.numel(), self._st()))
+        return idx, phys, w
+
+    def gather(self, phys):
+        """Batch assembly (dqn_per.py:415-452) on the device: six window tensors + a, r, done."""
+        B, d = phys.numel(), self.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=d)
+        out = dict(sprice=f(B, 25, 1), sprocess=f(B, 10, 6), sgas=f(B, 3, 2), nprice=f(B, 25, 1),
+                   nprocess=f(B, 10, 6), ngas=f(B, 3, 2), act=torch.empty(B, dtype=torch.int32, device=d),
+                   rew=f(B), done=f(B))
+        lib.check(lib.mctsq_per_gather(ptr(self.states), ptr(self.next_states), ptr(self.actions),
+                                       ptr(self.rewards), ptr(self.dones), ptr(phys), B, ptr(out["sprice"]),
+                                       ptr(out["sprocess"]), ptr(out["sgas"]), ptr(out["nprice"]),
+                                       ptr(out["nprocess"]), ptr(out["ngas"]), ptr(out["act"]), ptr(out["rew"]),
+                                       ptr(out["done"]), self._st()))
+        return out
+
+    # ---- priority write-back ----------------------------------------------------------
+    def update_priorities(self, idx, prio):
+        """prio[idx[i]] = p[i] in order (last duplicate wins), idx are LOGICAL indices."""
+        idx = torch.as_tensor(idx, dtype=torch.int64).to(self.device).contiguous()
+        prio = torch.as_tensor(prio, dtype=torch.float32).to(self.device).contiguous()
+        if idx.numel() != prio.numel():
+            raise ValueError("indices / priorities length mismatch")
+        lib.check(lib.mctsq_per_update(ptr(self.tree), ptr(self.prio), ptr(self.stamp), self.capacity, self.head, self.size,
+                                       ptr(idx), ptr(prio), idx.numel(), self.alpha, self._st()))
+        self._max_dirty = True
+
+    # ---- export (checkpoint interchange, dqn_per.py:487-492) ----------------------------
+    def logical_priorities(self):
+        p = self.prio.cpu().numpy()
+        order = (self.head + np.arange(self.size)) % self.capacity
+        return p[order]

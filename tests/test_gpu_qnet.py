@@ -1,0 +1,90 @@
+"""GPU parity: HIP Q-network forward (through the C ABI) vs golden vectors from the reference and
+vs the numpy/torch oracle on seeded inputs.  Tolerance (north_star): Q within 1e-5 relative
+(relative to max|Q| of the batch), greedy actions identical."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qnet_numpy, torch_ref
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BUILT_KINDS = None
+
+
+def _supported(cfg):
+    from mcts_q_amd.capabilities import supported_kinds
+    return all(cfg[k] in supported_kinds() for k in ("price", "process", "gas"))
+
+
+def _load(path):
+    z = np.load(path)
+    cfg = json.loads(str(z["cfg"]))
+    sd = {k[3:]: z[k] for k in z.files if k.startswith("sd/")}
+    if not sd:
+        torch.manual_seed(cfg["seed"])
+        sd = {k: v.detach().numpy() for k, v in torch_ref.RefQNet(cfg).state_dict().items()}
+    return z, cfg, sd
+
+
+QNET_FILES = sorted(glob.glob(os.path.join(GOLDEN, "qnet_*.npz")))
+
+
+@pytest.mark.parametrize("path", QNET_FILES, ids=[os.path.basename(p)[5:-4] for p in QNET_FILES])
+def test_forward_matches_reference_golden(path):
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(path)
+    if not _supported(cfg):
+        pytest.skip("encoder kind not built yet")
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    dev = [torch.from_numpy(z[k]).cuda() for k in ("price", "process", "gas")]
+    out = net(*dev)
+    torch.cuda.synchronize()
+    q = out["q"].cpu().numpy()
+    scale = np.abs(z["Q"]).max()
+    assert np.abs(q - z["Q"]).max() <= 1e-5 * scale
+    assert np.array_equal(out["argmax"].cpu().numpy(), z["argmax"])
+    np.testing.assert_allclose(out["vmax"].cpu().numpy(), z["vmax"], rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(out["prior"].cpu().numpy(), z["prior"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 17, 4096])
+@pytest.mark.parametrize("combo", [("gru", "gru", "gru")])
+def test_forward_matches_oracle_batched(combo, B):
+    """Ragged (non multiple of 16), single-leaf and the BASELINE config-2 batch."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, "qnet_%s_%s_%s_per_relu.npz" % combo))
+    if not _supported(cfg):
+        pytest.skip("encoder kind not built yet")
+    g = torch.Generator().manual_seed(B)
+    price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
+        torch.rand(B, 3, 2, generator=g)
+    ref64 = qnet_numpy.q_forward(sd, cfg, price.numpy(), process.numpy(), gas.numpy(), np.float64)
+    with torch.no_grad():
+        ref32 = torch_ref.RefQNet.from_state_dict(cfg, sd)(price, process, gas).numpy()
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    out = net(price.cuda(), process.cuda(), gas.cuda())
+    q = out["q"].cpu().numpy()
+    scale = np.abs(ref64).max()
+    err_hip, err_cpu = np.abs(q - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+    print(f"B={B}: HIP vs fp64 {err_hip:.2e}; torch-CPU vs fp64 {err_cpu:.2e}")
+    assert np.abs(q - ref32).max() <= 1e-5 * scale
+    assert err_hip <= 1e-5
+    # greedy action identical wherever the top-2 gap exceeds the tolerance
+    srt = np.sort(ref64, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2e-5 * scale
+    assert np.array_equal(out["argmax"].cpu().numpy()[clear], ref64.argmax(1)[clear])
+    np.testing.assert_allclose(out["vmax"].cpu().numpy(), q.max(1), rtol=0, atol=0)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import mcts_q_amd._lib as L
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmctsq_hip.so")
+    with pytest.raises(L.MctsqError):
+        L._Lib().mctsq_abi_version()
