@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmctsq_hip.so")
+LIB_PATH = os.environ.get("MCTSQ_HIP_LIB") or os.path.join(_HERE, "lib", "libmctsq_hip.so")
 
 
 class MctsqError(RuntimeError):

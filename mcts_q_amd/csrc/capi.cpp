@@ -89,9 +89,6 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
         if (e.kind == MCTSQ_ENC_GRU) fill_gru_slot(ga.slot[ga.nslots++], e, d_params, x[s], s);
         else MCTSQ_CHECK(false, "encoder kind %d is not built into this library yet", e.kind);
     }
-    if (launch_gru_fwd(ga, false, st)) return -1;
-    if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
-
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
@@ -100,6 +97,15 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
         ha.in[i] = L.fc_in[i]; ha.out[i] = L.fc_out[i];
     }
     ha.q = d_q; ha.vmax = d_vmax; ha.argmax = d_argmax; ha.prior = d_prior;
+
+    if (fused_gru_head_applicable(ga, ha)) {        // shipped default: one launch
+        ga.feats = nullptr;
+        if (launch_gru3_head_fwd(ga, ha, false, st)) return -1;
+        if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
+        return 0;
+    }
+    if (launch_gru_fwd(ga, false, st)) return -1;
+    if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
     return launch_head_fwd(ha, st);
 }
 

@@ -21,12 +21,28 @@ __device__ __forceinline__ f32x4 mfma16_x4(const float4& a, const float4& b, f32
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// sum over the 16 lanes that share lane>>4 (one MFMA output row group)
+// Hardware-rate transcendental forms (v_exp_f32 / v_rcp_f32, ~1 ulp each).  Absolute error of the
+// gates is ~1e-7, the same size as fp32 rounding of the O(1) values they produce; parity with the
+// fp64 oracle is checked in tests/test_gpu_qnet.py.
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return fast_rcp(1.0f + fast_exp2(-LOG2E * x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2((2.0f * LOG2E) * x));
+}
+
+// DPP move within rows of 16 lanes (row_ror:n = 0x120 + n)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes that share lane>>4 (one MFMA output row group); every lane gets the total
 __device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_row<0x128>(v);
+    v += dpp_row<0x124>(v);
+    v += dpp_row<0x122>(v);
+    v += dpp_row<0x121>(v);
     return v;
 }
 __device__ __forceinline__ float row16_max(float v) {

@@ -9,6 +9,7 @@
 namespace mctsq {
 
 constexpr int ALD = 260;   // LDS row stride (floats): max width 256 + 4
+constexpr int WL_FLOATS = 128 * 196;   // staged weight matrix, rows padded by 4 floats (25,088 floats)
 
 template <bool SAVE>
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
@@ -16,6 +17,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
     const int jl = lane & 15, q = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * TILE;
     __shared__ __attribute__((aligned(16))) float buf[2][TILE * ALD];
+    __shared__ __attribute__((aligned(16))) float wl[WL_FLOATS];
 
     for (int idx = tid; idx < TILE * (FEAT / 4); idx += 256) {      // feats tile, float4 copies
         const int i = idx / (FEAT / 4), c = idx - i * (FEAT / 4);
@@ -25,61 +27,93 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
     __syncthreads();
 
     for (int l = 0; l < a.n_fc; ++l) {
-        const int K = a.in[l], N = a.out[l], K4 = K >> 2, nt = (N + 15) >> 4;
-        const float* W = a.w[l];
+        const int K = a.in[l], N = a.out[l], K4 = K >> 2, KP = K + 4, kq = K >> 2;
         const float* src = buf[l & 1];
         float* dst = buf[(l + 1) & 1];
         const bool last = l == a.n_fc - 1;
         const float* xa = src + (lane & 15) * ALD + q * K4;
-        for (int t0 = w; t0 < nt; t0 += 8) {
-            const int jA = t0 * 16 + jl, jB = (t0 + 4) * 16 + jl;
-            const bool hasB = (t0 + 4) < nt;                       // wave-uniform
-            const bool okA = jA < N, okB = hasB && jB < N;
-            const float* wa = W + (int64_t)(okA ? jA : 0) * K + q * K4;
-            const float* wb = W + (int64_t)(okB ? jB : 0) * K + q * K4;
-            f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
-            const float4 zero4 = make_float4(0, 0, 0, 0);
-            if (hasB) {
-#pragma unroll 4
-                for (int kk = 0; kk < K4; kk += 4) {
-                    const float4 av = *reinterpret_cast<const float4*>(xa + kk);
-                    const float4 b1 = okA ? *reinterpret_cast<const float4*>(wa + kk) : zero4;
-                    const float4 b2 = okB ? *reinterpret_cast<const float4*>(wb + kk) : zero4;
-                    accA = mfma16(av.x, b1.x, accA); accB = mfma16(av.x, b2.x, accB);
-                    accA = mfma16(av.y, b1.y, accA); accB = mfma16(av.y, b2.y, accB);
-                    accA = mfma16(av.z, b1.z, accA); accB = mfma16(av.z, b2.z, accB);
-                    accA = mfma16(av.w, b1.w, accA); accB = mfma16(av.w, b2.w, accB);
-                }
-            } else {
-#pragma unroll 4
-                for (int kk = 0; kk < K4; kk += 4) {
-                    const float4 av = *reinterpret_cast<const float4*>(xa + kk);
-                    const float4 b1 = okA ? *reinterpret_cast<const float4*>(wa + kk) : zero4;
-                    accA = mfma16_x4(av, b1, accA);
-                }
-            }
-            if (okA) {
-                const float bias = a.b[l][jA];
+        // W[N][K] goes through LDS in chunks of NC output columns, staged with coalesced 16-byte
+        // loads (per-lane fragment reads from global would touch 64 cache lines per instruction);
+        // rows are padded to K+4 floats so the ds_read_b128 fragment reads are at most 2-way.
+        const int NC = min((WL_FLOATS / KP) & ~15, (N + 15) & ~15);
+        for (int n0 = 0; n0 < N; n0 += NC) {
+            const int nrows = min(NC, N - n0);
+            {   // 8 independent 16-byte loads in flight per lane before the first LDS write
+                const float4* gsrc = reinterpret_cast<const float4*>(a.w[l] + (int64_t)n0 * K);
+                const int total = nrows * kq;
+                for (int base = 0; base < total; base += 256 * 8) {
+                    float4 v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = accA[r] + bias;
-                    if (!last) v = apply_act(v, a.act);
-                    dst[(4 * q + r) * ALD + jA] = v;
-                    if (SAVE && !last) a.sv_act[l][(row0 + 4 * q + r) * (int64_t)N + jA] = v;
-                }
-            }
-            if (okB) {
-                const float bias = a.b[l][jB];
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = base + u * 256 + tid;
+                        v[u] = idx < total ? gsrc[idx] : make_float4(0, 0, 0, 0);
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = accB[r] + bias;
-                    if (!last) v = apply_act(v, a.act);
-                    dst[(4 * q + r) * ALD + jB] = v;
-                    if (SAVE && !last) a.sv_act[l][(row0 + 4 * q + r) * (int64_t)N + jB] = v;
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = base + u * 256 + tid;
+                        if (idx < total) {
+                            const int rj = idx / kq, c = idx - rj * kq;
+                            *reinterpret_cast<float4*>(&wl[rj * KP + 4 * c]) = v[u];
+                        }
+                    }
                 }
             }
+            __syncthreads();
+            const int nt = (nrows + 15) >> 4;
+            for (int t0 = w; t0 < nt; t0 += 8) {
+                const int jA = t0 * 16 + jl, jB = (t0 + 4) * 16 + jl;       // rows inside the chunk
+                const bool hasB = (t0 + 4) < nt;                           // wave-uniform
+                const bool okA = jA < nrows, okB = hasB && jB < nrows;
+                const float* wa = wl + (okA ? jA : 0) * KP + q * K4;
+                const float* wb = wl + (okB ? jB : 0) * KP + q * K4;
+                f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+                if (hasB) {
+#pragma unroll 2
+                    for (int kk = 0; kk < K4; kk += 4) {
+                        const float4 av = *reinterpret_cast<const float4*>(xa + kk);
+                        float4 b1 = *reinterpret_cast<const float4*>(wa + kk);
+                        float4 b2 = *reinterpret_cast<const float4*>(wb + kk);
+                        if (!okA) b1 = make_float4(0, 0, 0, 0);
+                        if (!okB) b2 = make_float4(0, 0, 0, 0);
+                        accA = mfma16(av.x, b1.x, accA); accB = mfma16(av.x, b2.x, accB);
+                        accA = mfma16(av.y, b1.y, accA); accB = mfma16(av.y, b2.y, accB);
+                        accA = mfma16(av.z, b1.z, accA); accB = mfma16(av.z, b2.z, accB);
+                        accA = mfma16(av.w, b1.w, accA); accB = mfma16(av.w, b2.w, accB);
+                    }
+                } else {
+#pragma unroll 2
+                    for (int kk = 0; kk < K4; kk += 4) {
+                        const float4 av = *reinterpret_cast<const float4*>(xa + kk);
+                        float4 b1 = *reinterpret_cast<const float4*>(wa + kk);
+                        if (!okA) b1 = make_float4(0, 0, 0, 0);
+                        accA = mfma16_x4(av, b1, accA);
+                    }
+                }
+                if (okA) {
+                    const int jg = n0 + jA;
+                    const float bias = a.b[l][jg];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = accA[r] + bias;
+                        if (!last) v = apply_act(v, a.act);
+                        dst[(4 * q + r) * ALD + jg] = v;
+                        if (SAVE && !last) a.sv_act[l][(row0 + 4 * q + r) * (int64_t)N + jg] = v;
+                    }
+                }
+                if (okB) {
+                    const int jg = n0 + jB;
+                    const float bias = a.b[l][jg];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = accB[r] + bias;
+                        if (!last) v = apply_act(v, a.act);
+                        dst[(4 * q + r) * ALD + jg] = v;
+                        if (SAVE && !last) a.sv_act[l][(row0 + 4 * q + r) * (int64_t)N + jg] = v;
+                    }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- epilogue: one lane per sample ------------------------------------------------

@@ -37,4 +37,8 @@ struct HeadArgs {
 };
 int launch_head_fwd(const HeadArgs& args, hipStream_t st);
 
+// gru/gru/gru + 192-128-128-A head in one launch (fused_gru_head.hip)
+bool fused_gru_head_applicable(const GruFwdArgs& ga, const HeadArgs& ha);
+int launch_gru3_head_fwd(const GruFwdArgs& ga, const HeadArgs& ha, bool save, hipStream_t st);
+
 }  // namespace mctsq

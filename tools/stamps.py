@@ -1,0 +1,30 @@
+"""Diagnostic: in-kernel s_memtime stamps of the fused kernel (needs a -DMCTSQ_STAMPS build)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from mcts_q_amd import NetSpec, lib
+from mcts_q_amd.qnet import DeviceQNet
+from oracle import torch_ref
+cfg = dict(price="gru", process="gru", gas="gru", act="relu", flavor="per")
+torch.manual_seed(0)
+sd = {k: v.detach().numpy() for k, v in torch_ref.RefQNet(cfg).state_dict().items()}
+net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+x = [torch.rand(B, 25, 1).cuda(), torch.rand(B, 10, 6).cuda(), torch.rand(B, 3, 2).cuda()]
+for _ in range(5):
+    net(*x)
+torch.cuda.synchronize()
+out = np.zeros(128, dtype=np.int64)
+lib._load().mctsq_debug_stamps.argtypes = [C.c_void_p]
+lib._load().mctsq_debug_stamps(out.ctypes.data)
+st = out[:64].reshape(4, 16)[:, :12]
+it = out[64:]
+print("wave0 per-iteration: work cycles (pre-barrier), barrier wait")
+for i in range(28):
+    prev = it[32 + i - 1] if i else st[1, 0]
+    print(i, it[i] - prev, it[32 + i] - it[i])
+print("ticks (100 MHz s_memtime => x10 ns) per wave: init+stage, gru loop, head")
+d = np.diff(st, axis=0)
+for w in range(12):
+    print(w, d[:, w], "total", st[3, w] - st[0, w])
+print("kernel span (all waves):", st[3].max() - st[0].min())
