@@ -108,13 +108,14 @@ int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float
 /* ---- clip_grad_norm_(max_norm) + Adam.step + Polyak target update (dqn_per.py:471-472,
  * 510-516) over the flat buffers, n floats each.  step is 1-based.  tau < 0 skips the target
  * update; tau == 1 is the hard copy of mctsq_config_dqn.py:547.  d_ws: >= 8 KiB scratch.
- * d_gnorm (optional) receives the pre-clip global L2 norm. */
+ * d_gnorm (optional) receives the pre-clip global L2 norm.  Hyper-parameters are doubles because
+ * the reference's are Python floats: torch forms 1-beta in fp64 before rounding to fp32. */
 int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
-                           float* d_target, int64_t n, int64_t step, float lr, float beta1,
-                           float beta2, float eps, float max_norm, float tau, float* d_gnorm,
+                           float* d_target, int64_t n, int64_t step, double lr, double beta1,
+                           double beta2, double eps, double max_norm, double tau, float* d_gnorm,
                            void* d_ws, int64_t ws_bytes, void* stream);
 /* Polyak / hard sync alone: target <- tau*policy + (1-tau)*target (dqn_per.py:515-516). */
-int mctsq_polyak(const float* d_params, float* d_target, int64_t n, float tau, void* stream);
+int mctsq_polyak(const float* d_params, float* d_target, int64_t n, double tau, void* stream);
 
 /* ---- prioritized replay: PrioritizedReplayBuffer (dqn_per.py:238-321) as a device-resident
  * ring + 64-ary integer sum-tree.  Logical index 0 is the OLDEST entry (deque(maxlen)).

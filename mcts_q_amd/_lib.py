@@ -37,9 +37,9 @@ SIGNATURES = {
     "mctsq_dqn_grad_workspace_bytes": (_i64, [_ND, _i64]),
     "mctsq_dqn_grad": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32,
                               _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "mctsq_clip_adam_polyak": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32,
-                                      _f32, _vp, _vp, _i64, _vp]),
-    "mctsq_polyak": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+    "mctsq_clip_adam_polyak": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64,
+                                      _f64, _vp, _vp, _i64, _vp]),
+    "mctsq_polyak": (_i32, [_vp, _vp, _i64, _f64, _vp]),
     "mctsq_per_tree_words": (_i64, [_i64]),
     "mctsq_per_mass_shift": (_i32, [_i64]),
     "mctsq_per_workspace_bytes": (_i64, [_i64, _i64]),

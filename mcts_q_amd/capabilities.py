@@ -1,6 +1,6 @@
 """Which encoder kinds the loaded libmctsq_hip.so implements (forward / training)."""
 FORWARD_KINDS = ("gru",)
-TRAIN_KINDS = ()
+TRAIN_KINDS = ("gru",)
 
 
 def supported_kinds():

@@ -7,15 +7,12 @@
 
 using namespace mctsq;
 
-namespace {
+#include "forward.hpp"
 
-// Build the per-slot argument records for the encoders of one forward pass.
-struct FwdPlan {
-    GruFwdArgs gru;
-    int gru_slots[3];
-};
+namespace mctsq {
 
-void fill_gru_slot(GruSlot& g, const EncOff& e, const float* params, const float* x, int slot) {
+static void fill_gru_slot(GruSlot& g, const EncOff& e, const float* params, const float* x, int slot,
+                          const SlotSave* sv) {
     memset(&g, 0, sizeof(g));
     g.x = x;
     g.wih = params + e.gru.wih; g.whh = params + e.gru.whh;
@@ -23,9 +20,56 @@ void fill_gru_slot(GruSlot& g, const EncOff& e, const float* params, const float
     g.aw = params + e.gru.aw;   g.ab = params + e.gru.ab;
     g.lnw = params + e.gru.lnw; g.lnb = params + e.gru.lnb;
     g.S = e.S; g.Fd = e.Fd; g.F = e.F; g.tf = e.tf; g.out_col = slot * E;
+    if (sv) {
+        g.sv_h = sv->h; g.sv_r = sv->r; g.sv_z = sv->z; g.sv_n = sv->n; g.sv_hn = sv->hn;
+        g.sv_score = sv->score; g.sv_stat = sv->stat; g.sv_pool = sv->pool; g.sv_x = sv->x;
+        g.bw_g = sv->g; g.bw_dsc = sv->dsc; g.bw_p = sv->p;
+    }
 }
 
-}  // namespace
+void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
+                   int64_t Bp, float* feats, const SlotSave* sv) {
+    memset(&ga, 0, sizeof(ga));
+    ga.B = B; ga.Bp = Bp; ga.feats = feats;
+    for (int s = 0; s < 3; ++s)
+        if (L.enc[s].kind == MCTSQ_ENC_GRU)
+            fill_gru_slot(ga.slot[ga.nslots++], L.enc[s], params, x[s], s, sv ? &sv[s] : nullptr);
+}
+
+// TripleEncoderDQN.forward (dqn_per.py:232-236) + leaf epilogue.  `sv` != NULL keeps the
+// activations the backward pass needs (training) and always takes the per-encoder kernels.
+int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
+                 float* feats, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
+                 void* ev_encoders_done) {
+    GruFwdArgs ga;
+    fill_gru_args(ga, L, params, x, B, Bp, feats, sv);
+    for (int s = 0; s < 3; ++s)
+        MCTSQ_CHECK(L.enc[s].kind == MCTSQ_ENC_GRU, "encoder kind %d is not built into this library yet",
+                    L.enc[s].kind);
+    HeadArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
+    for (int i = 0; i < L.n_fc; ++i) {
+        ha.w[i] = params + L.fc_w[i]; ha.b[i] = params + L.fc_b[i];
+        ha.in[i] = L.fc_in[i]; ha.out[i] = L.fc_out[i];
+    }
+    ha.q = out.q; ha.vmax = out.vmax; ha.argmax = out.argmax; ha.prior = out.prior;
+    const bool save = sv != nullptr;
+    if (save)
+        for (int i = 0; i + 1 < L.n_fc; ++i) ha.sv_act[i] = sv_act[i];
+
+    if (!save && fused_gru_head_applicable(ga, ha)) {        // shipped default: one launch
+        ga.feats = nullptr;
+        if (launch_gru3_head_fwd(ga, ha, false, st)) return -1;
+        if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
+        return 0;
+    }
+    if (launch_gru_fwd(ga, save, st)) return -1;
+    if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
+    return launch_head_fwd(ha, st);
+}
+
+}  // namespace mctsq
 
 extern "C" {
 
@@ -77,36 +121,10 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
     const int64_t Bp = round_up(B, TILE);
     MCTSQ_CHECK(d_ws && ws_bytes >= Bp * FEAT * (int64_t)sizeof(float), "workspace too small (%lld bytes)",
                 (long long)ws_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    float* feats = (float*)d_ws;
     const float* x[3] = {d_price, d_process, d_gas};
-
-    GruFwdArgs ga;
-    memset(&ga, 0, sizeof(ga));
-    ga.B = B; ga.Bp = Bp; ga.feats = feats;
-    for (int s = 0; s < 3; ++s) {
-        const EncOff& e = L.enc[s];
-        if (e.kind == MCTSQ_ENC_GRU) fill_gru_slot(ga.slot[ga.nslots++], e, d_params, x[s], s);
-        else MCTSQ_CHECK(false, "encoder kind %d is not built into this library yet", e.kind);
-    }
-    HeadArgs ha;
-    memset(&ha, 0, sizeof(ha));
-    ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
-    for (int i = 0; i < L.n_fc; ++i) {
-        ha.w[i] = d_params + L.fc_w[i]; ha.b[i] = d_params + L.fc_b[i];
-        ha.in[i] = L.fc_in[i]; ha.out[i] = L.fc_out[i];
-    }
-    ha.q = d_q; ha.vmax = d_vmax; ha.argmax = d_argmax; ha.prior = d_prior;
-
-    if (fused_gru_head_applicable(ga, ha)) {        // shipped default: one launch
-        ga.feats = nullptr;
-        if (launch_gru3_head_fwd(ga, ha, false, st)) return -1;
-        if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
-        return 0;
-    }
-    if (launch_gru_fwd(ga, false, st)) return -1;
-    if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
-    return launch_head_fwd(ha, st);
+    HeadOut out{d_q, d_vmax, d_argmax, d_prior};
+    return forward_impl(L, d_params, x, B, Bp, (float*)d_ws, out, nullptr, nullptr, (hipStream_t)stream,
+                        ev_encoders_done);
 }
 
 // ------------------------------------------------------------------------------- PER
@@ -194,16 +212,3 @@ int mctsq_per_gather(const float* d_states, const float* d_next_states, const in
 
 }  // extern "C"
 
-// -------- learner step: placeholder until learner.hip lands (symbols must exist for the ABI) -----
-extern "C" int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
-    (void)net; (void)B;
-    set_error("mctsq_dqn_grad is not built into this library yet");
-    return -1;
-}
-extern "C" int mctsq_dqn_grad(const mctsq_net_desc*, const float*, const float*, const float*, const float*,
-                              const float*, const float*, const float*, const float*, const int32_t*,
-                              const float*, const float*, const float*, float, float, int64_t, float*, float*,
-                              float*, float*, float*, void*, int64_t, void*) {
-    set_error("mctsq_dqn_grad is not built into this library yet");
-    return -1;
-}

@@ -64,18 +64,4 @@ int build_layout(const mctsq_net_desc* net, NetLayout* L);   // <0 on error (mes
 void host_time_features(int mode, int S, float* out);
 const char* last_error();
 
-// ---- kernel launchers (defined in the .hip files) ----
-struct FwdSave;   // training-time activation record, see learner.hpp
-int launch_gru_encoders(const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                        float* feats, const unsigned slot_mask, void* const* save, hipStream_t st);
-int launch_conv_encoders(const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                         float* feats, const unsigned slot_mask, void* const* save, hipStream_t st);
-int launch_mlp_encoder(const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                       float* feats, const unsigned slot_mask, void* const* save, hipStream_t st);
-int launch_tf_encoders(const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                       float* feats, const unsigned slot_mask, void* const* save, void* ws,
-                       hipStream_t st);
-int launch_head_fwd(const NetLayout& L, const float* params, const float* feats, int64_t B, float* q,
-                    float* vmax, int32_t* argmax, float* prior, float* save_h, hipStream_t st);
-
 }  // namespace mctsq

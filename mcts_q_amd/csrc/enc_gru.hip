@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void gru_enc_fwd_kernel(GruFwdArgs args) {
     __shared__ __attribute__((aligned(16))) GruLds L;
     GruWave<SAVE> g;
     g.init(s, threadIdx.x & 63, threadIdx.x >> 6);
-    g.stage(s, L, threadIdx.x, row0, args.B);
+    g.stage(s, L, threadIdx.x, row0, args.B, args.Bp);
     __syncthreads();
     for (int t = 0; t < s.S; ++t) {
         g.step(s, L, t, row0, args.Bp);

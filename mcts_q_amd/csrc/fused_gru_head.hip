@@ -43,7 +43,7 @@ __global__ __launch_bounds__(768) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     STAMP(0);
     GruWave<SAVE> g;
     g.init(s, lane, wq);
-    g.stage(s, G, gtid, row0, ga.B);
+    g.stage(s, G, gtid, row0, ga.B, ga.Bp);
     __syncthreads();
     STAMP(1);
 

@@ -57,7 +57,7 @@ struct GruWave {
     }
 
     // cooperative over the group's 256 lanes (gtid): xs[i][t*FP + f] (zero padded), hbuf[0] = 0
-    __device__ __forceinline__ void stage(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t B) {
+    __device__ __forceinline__ void stage(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t B, int64_t Bp) {
         const int S = s.S, F = s.F, Fd = s.Fd, SF = S * FP;
         for (int idx = gtid; idx < TILE * SF; idx += 256) {
             const int i = idx / SF, rem = idx - i * SF, t = rem / FP, f = rem - t * FP;
@@ -65,6 +65,15 @@ struct GruWave {
             if (row0 + i < B && f < F)
                 v = f < Fd ? s.x[(row0 + i) * (int64_t)(S * Fd) + t * Fd + f] : time_feature(s.tf, t, f - Fd);
             L.xs[i * XLD + rem] = v;
+            if (SAVE && f < 8) s.sv_x[((int64_t)t * Bp + row0 + i) * 8 + f] = v;
+        }
+        if (SAVE) {
+            if (FP == 4)
+                for (int idx = gtid; idx < TILE * S * 4; idx += 256) {
+                    const int i = idx / (S * 4), rem = idx - i * (S * 4), t = rem >> 2, f = 4 + (rem & 3);
+                    s.sv_x[((int64_t)t * Bp + row0 + i) * 8 + f] = 0.0f;
+                }
+            for (int idx = gtid; idx < TILE * E; idx += 256) s.sv_h[row0 * E + idx] = 0.0f;   // h_{-1}
         }
         for (int idx = gtid; idx < TILE * HLD; idx += 256) L.hbuf[0][idx] = 0.0f;
     }
@@ -119,7 +128,7 @@ struct GruWave {
             const float hnew = ng + zg * (h[r] - ng);
             if (SAVE) {
                 const int64_t o = ((int64_t)t * Bp + row0 + i) * E + j;
-                s.sv_r[o] = rg; s.sv_z[o] = zg; s.sv_n[o] = ng; s.sv_hn[o] = hn; s.sv_h[o] = hnew;
+                s.sv_r[o] = rg; s.sv_z[o] = zg; s.sv_n[o] = ng; s.sv_hn[o] = hn; s.sv_h[o + Bp * E] = hnew;
             }
             h[r] = hnew;
             L.hbuf[nxt][i * HLD + j] = hnew;

@@ -10,10 +10,16 @@ struct GruSlot {
     const float *wih, *whh, *bih, *bhh, *aw, *ab, *lnw, *lnb;
     int S, Fd, F, tf, out_col;
     // training-time activation record (NULL for inference), Bp = padded batch
-    float *sv_h, *sv_r, *sv_z, *sv_n, *sv_hn;   // [S][Bp][64]
-    float* sv_score;                     // [S][Bp]
+    float* sv_h;                         // [S+1][Bp][64]: block 0 = h_{-1} = 0, block t+1 = h_t
+    float *sv_r, *sv_z, *sv_n, *sv_hn;   // [S][Bp][64]
+    float* sv_score;                     // [S][Bp], log2 units
     float* sv_stat;                      // [Bp][4] = running max, running sum, LN mean, LN rstd
     float* sv_pool;                      // [Bp][64] pooled vector before LayerNorm
+    float* sv_x;                         // [S][Bp][8] time-major window incl. time features, zero padded
+    // backward outputs (learner.hip)
+    float* bw_g;                         // [S][Bp][256] = d(pre-activation) r | z | n | n*r
+    float* bw_dsc;                       // [S][Bp] d(score)
+    float* bw_p;                         // [Bp][64] dfeat * xhat (LayerNorm weight gradient terms)
 };
 struct GruFwdArgs {
     GruSlot slot[3];
@@ -21,7 +27,6 @@ struct GruFwdArgs {
     int64_t B, Bp;
     float* feats;                        // [Bp][192]
 };
-inline int64_t gru_save_floats(int S, int64_t Bp) { return 5 * (int64_t)S * Bp * E + (int64_t)S * Bp + 4 * Bp + E * Bp; }
 int launch_gru_fwd(const GruFwdArgs& args, bool save, hipStream_t st);
 
 // ---------------- head ----------------

@@ -1,0 +1,361 @@
+// Learner kernels: TD loss, head backward, GRU-attention backward (BPTT), weight-gradient GEMMs.
+// Together with the SAVE variants of the forward kernels they are loss.backward() of
+// DQNModel.update (dqn_per.py:455-470), written out by hand.
+//
+// Structure: the backward kernels only produce "delta" arrays (gradients w.r.t. pre-activations)
+// tile by tile; every weight/bias gradient is then a K = batch(*time) contraction
+// dW = delta^T . input, done by one generic split-K MFMA kernel whose partials are reduced in a
+// fixed order (bitwise reproducible, no float atomics).
+#include "device_utils.hpp"
+#include "learner.hpp"
+
+namespace mctsq {
+
+// ================================================================================ TD loss
+__global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < a.Bp; i += 1024) {
+        float g = 0.0f;
+        int ac = -1;
+        if (i < a.B) {
+            ac = a.act[i];
+            const bool ok = ac >= 0 && ac < a.A;
+            const float qsa = ok ? a.q[i * a.A + ac] : 0.0f;
+            // rewards + gamma * next_q * (1 - dones), evaluated left to right as torch does (:464)
+            const float y = __fadd_rn(a.rew[i], __fmul_rn(__fmul_rn(a.gamma, a.qnext[i]), 1.0f - a.done[i]));
+            const float td = qsa - y;
+            const float w = a.isw[i];
+            acc += (double)__fmul_rn(w, __fmul_rn(td, td));
+            g = ok ? a.grad_scale * w * td : 0.0f;
+            if (!ok) ac = -1;
+            a.abs_td[i] = fabsf(td);
+            if (a.qsa) a.qsa[i] = qsa;
+            if (a.target) a.target[i] = y;
+        }
+        float4* row = reinterpret_cast<float4*>(a.dq + i * DQ_LD);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 v = make_float4(0, 0, 0, 0);
+            if ((ac >> 2) == c) (&v.x)[ac & 3] = g;
+            row[c] = v;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        *a.loss = (float)(t / (double)a.B);
+    }
+}
+
+int launch_td_loss(const TdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ============================================================================ head backward
+// One workgroup = 16 samples.  d(out) [16 x K] sits in LDS; d(in)[i][n] = sum_k d(out)[i][k] W[k][n]
+// is a [16 x K].[K x N] MFMA product with W read row-wise (coalesced 64-byte segments, L2
+// resident), then masked by the activation derivative of the layer below.
+constexpr int BLD = 260;
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float d[2][TILE * BLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jl = lane & 15, q = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * TILE;
+    for (int idx = tid; idx < TILE * DQ_LD; idx += 256) {
+        const int i = idx / DQ_LD, c = idx - i * DQ_LD;
+        d[0][i * BLD + c] = a.dq[(row0 + i) * DQ_LD + c];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int l = a.n_fc - 1; l >= 0; --l) {
+        const int K = a.out[l], N = a.in[l];
+        const int Kp = (K + 15) & ~15, K4 = Kp >> 2;            // lane group q covers k in [q*K4, (q+1)*K4)
+        const float* W = a.w[l];
+        const float* src = d[cur] + (lane & 15) * BLD + q * K4;
+        float* dst = d[cur ^ 1];
+        for (int nt = w; nt < (N >> 4); nt += 4) {
+            const int n = nt * 16 + jl;
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            for (int kk = 0; kk < K4; kk += 4) {
+                const float4 av = *reinterpret_cast<const float4*>(src + kk);
+                const int k = q * K4 + kk;
+                const float b0 = k + 0 < K ? W[(int64_t)(k + 0) * N + n] : 0.0f;
+                const float b1 = k + 1 < K ? W[(int64_t)(k + 1) * N + n] : 0.0f;
+                const float b2 = k + 2 < K ? W[(int64_t)(k + 2) * N + n] : 0.0f;
+                const float b3 = k + 3 < K ? W[(int64_t)(k + 3) * N + n] : 0.0f;
+                acc0 = mfma16(av.x, b0, acc0); acc1 = mfma16(av.y, b1, acc1);
+                acc0 = mfma16(av.z, b2, acc0); acc1 = mfma16(av.w, b3, acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * q + r;
+                float v = acc0[r] + acc1[r];
+                if (l > 0) {
+                    const float h = a.sv_act[l - 1][row * N + n];
+                    v = a.act == MCTSQ_ACT_RELU ? (h > 0.0f ? v : 0.0f) : v * (1.0f - h * h);
+                    a.d_act[l - 1][row * N + n] = v;
+                    dst[(4 * q + r) * BLD + n] = v;
+                } else {
+                    a.dfeat[row * N + n] = v;
+                }
+            }
+        }
+        // zero the k padding the next layer reads (N is a multiple of 16, so nothing to pad)
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
+    for (int l = 0; l < a.n_fc; ++l) {
+        MCTSQ_CHECK(a.in[l] % 16 == 0 && a.in[l] <= 256, "head backward layer %d: width %d unsupported", l, a.in[l]);
+        MCTSQ_CHECK(a.out[l] <= 256, "head backward layer %d: width %d unsupported", l, a.out[l]);
+    }
+    MCTSQ_CHECK(a.out[a.n_fc - 1] <= DQ_LD, "action_dim > %d", DQ_LD);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(a.Bp / TILE)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ================================================================= GRU-attention backward
+// dqn_per.py:72-77 differentiated by hand.  One workgroup (4 waves) per (16-sample tile, slot),
+// the same ownership as the forward: wave wq holds hidden units 16wq..16wq+15, lane register r is
+// sample 4q+r.  Per step the hidden-state gradient needs [16 x 192].[192 x 64] (delta . W_hh):
+// delta goes through a double-buffered LDS tile, W_hh columns stay in 48 VGPRs per lane.
+constexpr int GLD = 196;     // LDS row stride of the delta tile (192 + 4)
+
+struct GruBwdLds {
+    float g[2][TILE * GLD];
+    float4 pe[MAX_SEQ][TILE];       // per-wave partials of e_t = dpool . h_t
+    float red[3][4][TILE];
+};
+
+__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
+    __shared__ __attribute__((aligned(16))) GruBwdLds L;
+    const int slot = blockIdx.x % args.nslots;
+    const int64_t row0 = (int64_t)(blockIdx.x / args.nslots) * TILE;
+    const GruSlot& s = args.slot[slot];
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6, jl = lane & 15, q = lane >> 4;
+    const int j = 16 * wq + jl;
+    const int S = s.S;
+    const int64_t Bp = args.Bp;
+
+    // W_hh columns: B operand of the delta . W_hh product, k = 48q + c (gate row), col = unit j
+    float wf[48];
+#pragma unroll
+    for (int c = 0; c < 48; ++c) wf[c] = s.whh[(int64_t)(48 * q + c) * E + j];
+    const float lnw = s.lnw[j], awj = s.aw[j];
+
+    // ---- LayerNorm backward -> dpool -------------------------------------------------------
+    float dpool[4], pooled[4], mrun[4], linv[4];
+    {
+        float dxh[4], xh[4], rs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * q + r;
+            const float4 st = *reinterpret_cast<const float4*>(s.sv_stat + row * 4);
+            mrun[r] = st.x; linv[r] = 1.0f / st.y; rs[r] = st.w;
+            pooled[r] = s.sv_pool[row * E + j];
+            const float df = args.dfeat[row * FEAT + s.out_col + j];
+            xh[r] = (pooled[r] - st.z) * st.w;
+            dxh[r] = df * lnw;
+            s.bw_p[row * E + j] = df * xh[r];
+            const float s1 = row16_sum(dxh[r]), s2 = row16_sum(dxh[r] * xh[r]);
+            if (jl == 0) { L.red[0][wq][4 * q + r] = s1; L.red[1][wq][4 * q + r] = s2; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            const float s1 = ((L.red[0][0][i] + L.red[0][1][i]) + (L.red[0][2][i] + L.red[0][3][i])) * (1.0f / E);
+            const float s2 = ((L.red[1][0][i] + L.red[1][1][i]) + (L.red[1][2][i] + L.red[1][3][i])) * (1.0f / E);
+            dpool[r] = rs[r] * (dxh[r] - s1 - xh[r] * s2);
+        }
+    }
+    // ---- attention pooling backward: D = dpool . pooled, e_t = dpool . h_t ---------------
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = row16_sum(dpool[r] * pooled[r]);
+        if (jl == 0) L.red[2][wq][4 * q + r] = v;
+    }
+    for (int t = 0; t < S; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h = s.sv_h[((int64_t)(t + 1) * Bp + row0 + 4 * q + r) * E + j];
+            const float v = row16_sum(dpool[r] * h);
+            if (jl == 0) (&L.pe[t][4 * q + r].x)[wq] = v;
+        }
+    }
+    __syncthreads();
+    float Dd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * q + r;
+        Dd[r] = (L.red[2][0][i] + L.red[2][1][i]) + (L.red[2][2][i] + L.red[2][3][i]);
+    }
+
+    // ---- BPTT ----------------------------------------------------------------------------
+    float dhc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = S - 1; t >= 0; --t) {
+        const int buf = t & 1;
+        float zs[4], dhs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            const int64_t row = (int64_t)t * Bp + row0 + i;
+            const int64_t o = row * E + j;
+            const float rg = s.sv_r[o], zg = s.sv_z[o], ng = s.sv_n[o], hn = s.sv_hn[o];
+            const float hprev = s.sv_h[o];                      // block t = h_{t-1}
+            const float sc = s.sv_score[row];
+            const float at = fast_exp2(sc - mrun[r]) * linv[r];
+            const float4 pe = L.pe[t][i];
+            const float dsc = at * (((pe.x + pe.y) + (pe.z + pe.w)) - Dd[r]);
+            if (wq == 0 && jl == 0) s.bw_dsc[row] = dsc;
+            const float dh = dhc[r] + at * dpool[r] + dsc * awj;
+            const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
+            const float dzp = dh * (hprev - ng) * zg * (1.0f - zg);
+            const float drp = dnp * hn * rg * (1.0f - rg);
+            const float ghn = dnp * rg;
+            float* grow = s.bw_g + row * 256;
+            grow[j] = drp; grow[E + j] = dzp; grow[2 * E + j] = dnp; grow[3 * E + j] = ghn;
+            float* lrow = &L.g[buf][i * GLD];
+            lrow[j] = drp; lrow[E + j] = dzp; lrow[2 * E + j] = ghn;
+            zs[r] = zg; dhs[r] = dh;
+        }
+        if (t == 0) break;                                     // dh_{-1} is not needed
+        __syncthreads();
+        const float4* ga = reinterpret_cast<const float4*>(&L.g[buf][(lane & 15) * GLD + 48 * q]);
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a0 = ga[c], a1 = ga[4 + c], a2 = ga[8 + c];
+            acc0 = mfma16(a0.x, wf[4 * c + 0], acc0); acc1 = mfma16(a1.x, wf[16 + 4 * c + 0], acc1); acc2 = mfma16(a2.x, wf[32 + 4 * c + 0], acc2);
+            acc0 = mfma16(a0.y, wf[4 * c + 1], acc0); acc1 = mfma16(a1.y, wf[16 + 4 * c + 1], acc1); acc2 = mfma16(a2.y, wf[32 + 4 * c + 1], acc2);
+            acc0 = mfma16(a0.z, wf[4 * c + 2], acc0); acc1 = mfma16(a1.z, wf[16 + 4 * c + 2], acc1); acc2 = mfma16(a2.z, wf[32 + 4 * c + 2], acc2);
+            acc0 = mfma16(a0.w, wf[4 * c + 3], acc0); acc1 = mfma16(a1.w, wf[16 + 4 * c + 3], acc1); acc2 = mfma16(a2.w, wf[32 + 4 * c + 3], acc2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dhc[r] = dhs[r] * zs[r] + ((acc0[r] + acc1[r]) + acc2[r]);
+    }
+}
+
+int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
+    if (a.nslots == 0) return 0;
+    MCTSQ_CHECK(a.Bp % TILE == 0, "padded batch must be a multiple of %d", TILE);
+    for (int i = 0; i < a.nslots; ++i) MCTSQ_CHECK(a.slot[i].S <= MAX_SEQ, "window too long");
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)(a.Bp / TILE * a.nslots)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ====================================================================== weight-gradient GEMM
+// Block = 4 waves = a 64 x 64 output tile of one (job, K split); wave w owns rows 16w..16w+15.
+// A operand lane (m = l&15, k = l>>4) reads A[k0+k][m]; B operand lane (n = l&15, k = l>>4) reads
+// Bm[k0+k][n]: both are 4 rows x 64 contiguous bytes per wave instruction.
+__global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, float* __restrict__ partials) {
+    int ji = 0;
+    for (int k = 1; k < jl.njobs; ++k)
+        if ((int)blockIdx.x >= jl.job[k].blk0) ji = k;
+    const WJob& J = jl.job[ji];
+    const int lb = blockIdx.x - J.blk0, per = J.mblocks * J.nblocks;
+    const int split = lb / per, rem = lb - split * per, mb = rem / J.nblocks, nb = rem - mb * J.nblocks;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jl_ = lane & 15, q = lane >> 4;
+    const int M = J.M, N = J.N;
+    const int m0 = mb * 64 + 16 * w, n0 = nb * 64;
+    if (m0 >= M) return;
+    const int64_t k0 = (int64_t)split * J.kchunk;
+    const int64_t k1 = k0 + J.kchunk < J.K ? k0 + J.kchunk : J.K;
+    const bool m_ok = m0 + jl_ < M;
+    const bool do_bias = nb == 0;
+    const int ntile = J.Bm ? min(4, (N - n0 + 15) >> 4) : 0;
+    const float* ap = J.A + (k0 + q) * J.lda + J.a_col0 + m0 + jl_;
+    const float* bp = J.Bm ? J.Bm + (k0 + q) * J.ldb + J.b_col0 + n0 + jl_ : nullptr;
+    bool n_ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) n_ok[t] = t < ntile && n0 + 16 * t + jl_ < N;
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    f32x4 accb = {0, 0, 0, 0};
+    const int64_t astep = 4 * J.lda, bstep = J.Bm ? 4 * J.ldb : 0;
+#pragma unroll 4
+    for (int64_t k = k0; k < k1; k += 4) {
+        const float av = m_ok ? *ap : 0.0f;
+        ap += astep;
+        if (ntile > 0) acc[0] = mfma16(av, n_ok[0] ? bp[0] : 0.0f, acc[0]);
+        if (ntile > 1) acc[1] = mfma16(av, n_ok[1] ? bp[16] : 0.0f, acc[1]);
+        if (ntile > 2) acc[2] = mfma16(av, n_ok[2] ? bp[32] : 0.0f, acc[2]);
+        if (ntile > 3) acc[3] = mfma16(av, n_ok[3] ? bp[48] : 0.0f, acc[3]);
+        if (do_bias) accb = mfma16(av, 1.0f, accb);
+        bp += bstep;
+    }
+    float* P = partials + J.part_off + (int64_t)split * ((int64_t)M * N + M);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < ntile) {
+            const int n = n0 + 16 * t + jl_;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 4 * q + r;
+                if (m < M && n < N) P[(int64_t)m * N + n] = acc[t][r];
+            }
+        }
+    }
+    if (do_bias && jl_ == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * q + r;
+            if (m < M) P[(int64_t)M * N + m] = accb[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const float* __restrict__ partials,
+                                                           float* __restrict__ grad, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int64_t base = 0;
+    int ji = 0;
+    for (; ji < jl.njobs; ++ji) {
+        const int64_t n = (int64_t)jl.job[ji].M * jl.job[ji].N + jl.job[ji].M;
+        if (e < base + n) break;
+        base += n;
+    }
+    const WJob& J = jl.job[ji];
+    const int64_t le = e - base, mn = (int64_t)J.M * J.N, stride = mn + J.M;
+    const float* p = partials + J.part_off + le;
+    float acc = 0.0f;
+    for (int sp = 0; sp < J.nsplit; ++sp) acc += p[(int64_t)sp * stride];
+    if (le < mn) {
+        if (J.out_w >= 0 && J.Bm) {
+            const int64_t m = le / J.N, n = le - m * J.N;
+            grad[J.out_w + m * J.out_ldm + n * J.out_sn] = acc;
+        }
+    } else if (J.out_b >= 0) {
+        grad[J.out_b + (le - mn)] = acc;
+    }
+}
+
+int launch_wgrad(const WJobList& jl, float* partials, hipStream_t st) {
+    if (jl.njobs == 0) return 0;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)jl.nblocks_total), dim3(256), 0, st, jl, partials);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, hipStream_t st) {
+    if (jl.njobs == 0) return 0;
+    int64_t total = 0;
+    for (int i = 0; i < jl.njobs; ++i) total += (int64_t)jl.job[i].M * jl.job[i].N + jl.job[i].M;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, jl, partials,
+                       grad, total);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mctsq

@@ -1,0 +1,65 @@
+// Learner-side records: TD loss, head / encoder backward, weight-gradient GEMM jobs.
+// DQNModel.update (dqn_per.py:455-472) between the batch gather and the optimizer step.
+#pragma once
+#include "kernels.hpp"
+
+namespace mctsq {
+
+constexpr int DQ_LD = 16;       // dQ rows are padded to 16 action columns (zeros beyond A)
+constexpr int MAX_WJOBS = 16;   // jobs per wgrad launch (kernel-argument budget)
+
+// ---- TD loss (dqn_per.py:455-467, 474) ----
+struct TdArgs {
+    const float* q;             // [B][A] policy Q(s)
+    const float* qnext;         // [B] max_a' Q_target(s')
+    const int32_t* act;
+    const float *rew, *done, *isw;
+    float gamma, grad_scale;    // grad_scale = loss_scale * 2 / B
+    int64_t B, Bp;
+    int A;
+    float* dq;                  // [Bp][16]
+    float *loss, *abs_td, *qsa, *target;
+};
+int launch_td_loss(const TdArgs& a, hipStream_t st);
+
+// ---- head backward ----
+struct HeadBwdArgs {
+    const float* w[5];          // W[l] [out][in]
+    int n_fc, in[5], out[5], act;
+    int64_t Bp;
+    const float* dq;            // [Bp][16]
+    const float* sv_act[4];     // post-activation hidden layers [Bp][H]
+    float* d_act[4];            // out: d(pre-activation) of hidden layer l, [Bp][H]
+    float* dfeat;               // out: [Bp][192]
+};
+int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);
+
+// ---- GRU-attention backward: LayerNorm, attention pooling, BPTT (deltas only) ----
+struct GruBwdArgs {
+    GruSlot slot[3];
+    int nslots;
+    int64_t Bp;
+    const float* dfeat;         // [Bp][192]
+};
+int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
+
+// ---- weight gradients: dW[m][n] = sum_k A[k][m] * Bm[k][n], bias[m] = sum_k A[k][m] ----
+// Split over K into `nsplit` chunks whose partial results are reduced in a fixed order, so the
+// gradient is bitwise reproducible (no float atomics).
+struct WJob {
+    const float* A;             // [K][lda], columns a_col0 .. a_col0+M-1
+    const float* Bm;            // [K][ldb], columns b_col0 .. b_col0+N-1 (NULL: bias only)
+    int64_t lda, ldb, K, kchunk;
+    int64_t part_off;           // float offset of this job's partials: [nsplit][M*N + M]
+    int64_t out_w, out_ldm, out_sn;   // grad index = out_w + m*out_ldm + n*out_sn (out_w < 0: none)
+    int64_t out_b;              // bias gradient offset (< 0: none)
+    int a_col0, b_col0, M, N, nsplit, mblocks, nblocks, blk0;
+};
+struct WJobList {
+    WJob job[MAX_WJOBS];
+    int njobs, nblocks_total;
+};
+int launch_wgrad(const WJobList& jl, float* partials, hipStream_t st);
+int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, hipStream_t st);
+
+}  // namespace mctsq

@@ -1,0 +1,225 @@
+// mctsq_dqn_grad: the learner step of DQNModel.update (dqn_per.py:455-470) on an already gathered
+// batch.  Host side: carve the caller's workspace, enqueue target forward -> policy forward (keeping
+// activations) -> TD loss -> head backward -> encoder backward -> weight-gradient GEMMs -> ordered
+// reduction into the flat gradient buffer.  Everything runs on the caller's stream.
+#include <string.h>
+
+#include "forward.hpp"
+#include "learner.hpp"
+
+using namespace mctsq;
+
+namespace {
+
+struct Carver {
+    int64_t pos = 0;                                     // floats
+    int64_t take(int64_t n) {
+        const int64_t at = pos;
+        pos = (pos + n + 63) & ~int64_t(63);            // 256-byte aligned blocks
+        return at;
+    }
+};
+
+struct GruPlan { int64_t h, r, z, n, hn, score, stat, pool, x, g, dsc, p; };
+
+struct TrainPlan {
+    int64_t Bp;
+    int64_t feats_t, q_t, qnext, feats_p, q_p, dq, dfeat;
+    int64_t act[4], dact[4];
+    GruPlan gru[3];
+    int64_t partials, partial_floats;
+    int64_t total;                                       // floats
+};
+
+int64_t split_chunk(int64_t K) {                         // K chunk per split: <= 64 splits, >= 64 rows
+    int64_t c = (K + 63) / 64;
+    if (c < 64) c = 64;
+    return (c + 3) & ~int64_t(3);
+}
+int64_t job_partial_floats(int M, int N, int64_t K) {
+    const int64_t kc = split_chunk(K), ns = (K + kc - 1) / kc;
+    return ns * ((int64_t)M * N + M);
+}
+
+int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
+    memset(P, 0, sizeof(*P));
+    const int64_t Bp = round_up(B > 0 ? B : 1, TILE);
+    P->Bp = Bp;
+    Carver c;
+    P->feats_t = c.take(Bp * FEAT); P->q_t = c.take(Bp * L.A); P->qnext = c.take(Bp);
+    P->feats_p = c.take(Bp * FEAT); P->q_p = c.take(Bp * L.A);
+    P->dq = c.take(Bp * DQ_LD); P->dfeat = c.take(Bp * FEAT);
+    for (int i = 0; i + 1 < L.n_fc; ++i) {
+        P->act[i] = c.take(Bp * L.fc_out[i]);
+        P->dact[i] = c.take(Bp * L.fc_out[i]);
+    }
+    int64_t pf = 0;
+    for (int s = 0; s < 3; ++s) {
+        const EncOff& e = L.enc[s];
+        const int64_t S = e.S;
+        MCTSQ_CHECK(e.kind == MCTSQ_ENC_GRU, "training path: encoder kind %d is not built into this library yet", e.kind);
+        GruPlan& g = P->gru[s];
+        g.h = c.take((S + 1) * Bp * E);
+        g.r = c.take(S * Bp * E); g.z = c.take(S * Bp * E); g.n = c.take(S * Bp * E); g.hn = c.take(S * Bp * E);
+        g.score = c.take(S * Bp); g.stat = c.take(Bp * 4); g.pool = c.take(Bp * E); g.x = c.take(S * Bp * 8);
+        g.g = c.take(S * Bp * 256); g.dsc = c.take(S * Bp); g.p = c.take(Bp * E);
+        const int64_t K = S * Bp;
+        pf += job_partial_floats(G3, e.F, K) + job_partial_floats(128, E, K) + job_partial_floats(E, E, K) +
+              job_partial_floats(1, E, K) + 2 * job_partial_floats(E, 0, Bp);
+    }
+    for (int i = 0; i < L.n_fc; ++i) pf += job_partial_floats(L.fc_out[i], L.fc_in[i], Bp);
+    P->partial_floats = pf;
+    P->partials = c.take(pf);
+    P->total = c.pos;
+    return 0;
+}
+
+struct JobBuilder {
+    WJobList lists[4];
+    int nlists = 0;
+    int64_t part_pos = 0;
+    JobBuilder() { memset(lists, 0, sizeof(lists)); }
+    int add(const float* A, int64_t lda, int a_col0, const float* Bm, int64_t ldb, int b_col0, int M, int N,
+            int64_t K, int64_t out_w, int64_t out_ldm, int64_t out_sn, int64_t out_b) {
+        if (nlists == 0 || lists[nlists - 1].njobs == MAX_WJOBS) {
+            MCTSQ_CHECK(nlists < 4, "too many weight-gradient jobs");
+            ++nlists;
+        }
+        WJobList& jl = lists[nlists - 1];
+        WJob& j = jl.job[jl.njobs++];
+        j.A = A; j.lda = lda; j.a_col0 = a_col0; j.Bm = Bm; j.ldb = ldb; j.b_col0 = b_col0;
+        j.M = M; j.N = Bm ? N : 0; j.K = K;
+        j.kchunk = split_chunk(K);
+        j.nsplit = (int)((K + j.kchunk - 1) / j.kchunk);
+        j.part_off = part_pos;
+        part_pos += (int64_t)j.nsplit * ((int64_t)j.M * j.N + j.M);
+        j.out_w = Bm ? out_w : -1; j.out_ldm = out_ldm; j.out_sn = out_sn; j.out_b = out_b;
+        j.mblocks = (M + 63) / 64;
+        j.nblocks = j.N > 0 ? (j.N + 63) / 64 : 1;
+        j.blk0 = jl.nblocks_total;
+        jl.nblocks_total += j.nsplit * j.mblocks * j.nblocks;
+        MCTSQ_CHECK(K % 4 == 0, "weight-gradient contraction length must be a multiple of 4");
+        return 0;
+    }
+};
+
+}  // namespace
+
+extern "C" int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    if (B < 0) { set_error("negative batch"); return -1; }
+    TrainPlan P;
+    if (make_plan(L, B, &P)) return -1;
+    return P.total * (int64_t)sizeof(float);
+}
+
+extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
+                              const float* d_sprice, const float* d_sprocess, const float* d_sgas,
+                              const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                              const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
+                              float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss,
+                              float* d_abs_td, float* d_qsa, float* d_target, void* d_ws, int64_t ws_bytes,
+                              void* stream) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    MCTSQ_CHECK(B >= 1, "batch must be >= 1");
+    MCTSQ_CHECK(d_params && d_target_params && d_sprice && d_sprocess && d_sgas && d_nprice && d_nprocess &&
+                    d_ngas && d_act && d_rew && d_done && d_isw && d_grad && d_loss && d_abs_td,
+                "NULL device pointer");
+    TrainPlan P;
+    if (make_plan(L, B, &P)) return -1;
+    MCTSQ_CHECK(d_ws && ws_bytes >= P.total * (int64_t)sizeof(float), "workspace too small: %lld < %lld bytes",
+                (long long)ws_bytes, (long long)(P.total * (int64_t)sizeof(float)));
+    MCTSQ_CHECK(((uintptr_t)d_ws & 15) == 0, "workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)d_ws;
+    const int64_t Bp = P.Bp;
+
+    // 1. target network on s' -> max_a' Q (dqn_per.py:460-463)
+    {
+        const float* x[3] = {d_nprice, d_nprocess, d_ngas};
+        HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
+        if (forward_impl(L, d_target_params, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, st, nullptr)) return -1;
+    }
+    // 2. policy network on s, activations kept (dqn_per.py:455-457)
+    SlotSave sv[3];
+    memset(sv, 0, sizeof(sv));
+    for (int s = 0; s < 3; ++s) {
+        const GruPlan& g = P.gru[s];
+        sv[s].h = ws + g.h; sv[s].r = ws + g.r; sv[s].z = ws + g.z; sv[s].n = ws + g.n; sv[s].hn = ws + g.hn;
+        sv[s].score = ws + g.score; sv[s].stat = ws + g.stat; sv[s].pool = ws + g.pool; sv[s].x = ws + g.x;
+        sv[s].g = ws + g.g; sv[s].dsc = ws + g.dsc; sv[s].p = ws + g.p;
+    }
+    float* sv_act[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i + 1 < L.n_fc; ++i) sv_act[i] = ws + P.act[i];
+    const float* xs[3] = {d_sprice, d_sprocess, d_sgas};
+    {
+        HeadOut out{ws + P.q_p, nullptr, nullptr, nullptr};
+        if (forward_impl(L, d_params, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr)) return -1;
+    }
+    // 3. TD target, IS-weighted MSE, dLoss/dQ, new priorities (dqn_per.py:464-467, 474)
+    {
+        TdArgs t;
+        memset(&t, 0, sizeof(t));
+        t.q = ws + P.q_p; t.qnext = ws + P.qnext; t.act = d_act; t.rew = d_rew; t.done = d_done; t.isw = d_isw;
+        t.gamma = gamma; t.grad_scale = loss_scale * 2.0f / (float)B; t.B = B; t.Bp = Bp; t.A = L.A;
+        t.dq = ws + P.dq; t.loss = d_loss; t.abs_td = d_abs_td; t.qsa = d_qsa; t.target = d_target;
+        if (launch_td_loss(t, st)) return -1;
+    }
+    // 4. head backward
+    {
+        HeadBwdArgs h;
+        memset(&h, 0, sizeof(h));
+        h.n_fc = L.n_fc; h.act = L.act; h.Bp = Bp; h.dq = ws + P.dq; h.dfeat = ws + P.dfeat;
+        for (int i = 0; i < L.n_fc; ++i) { h.w[i] = d_params + L.fc_w[i]; h.in[i] = L.fc_in[i]; h.out[i] = L.fc_out[i]; }
+        for (int i = 0; i + 1 < L.n_fc; ++i) { h.sv_act[i] = ws + P.act[i]; h.d_act[i] = ws + P.dact[i]; }
+        if (launch_head_bwd(h, st)) return -1;
+    }
+    // 5. encoder backward (deltas)
+    {
+        GruFwdArgs ga;
+        fill_gru_args(ga, L, d_params, xs, B, Bp, ws + P.feats_p, sv);
+        GruBwdArgs gb;
+        memset(&gb, 0, sizeof(gb));
+        gb.nslots = ga.nslots; gb.Bp = Bp; gb.dfeat = ws + P.dfeat;
+        for (int i = 0; i < ga.nslots; ++i) gb.slot[i] = ga.slot[i];
+        if (launch_gru_bwd(gb, st)) return -1;
+    }
+    // 6. weight gradients: every tensor is one (or a few) K-contractions
+    JobBuilder jb;
+    for (int s = 0; s < 3; ++s) {
+        const EncOff& e = L.enc[s];
+        const GruPlan& g = P.gru[s];
+        const int64_t K = (int64_t)e.S * Bp;
+        const float* G = ws + g.g;
+        const float* Hprev = ws + g.h;                    // block t = h_{t-1}
+        const float* Hcur = ws + g.h + Bp * E;            // block t+1 = h_t
+        // W_ih [192][F] + b_ih: delta (r|z|n) x x_t
+        if (jb.add(G, 256, 0, ws + g.x, 8, 0, G3, e.F, K, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
+        // W_hh rows r,z + b_hh[0:128]: delta (r|z) x h_{t-1}
+        if (jb.add(G, 256, 0, Hprev, E, 0, 2 * E, E, K, e.gru.whh, E, 1, e.gru.bhh)) return -1;
+        // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1}
+        if (jb.add(G, 256, 3 * E, Hprev, E, 0, E, E, K, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E)) return -1;
+        // attention score Linear(64,1): d(score) x h_t
+        if (jb.add(ws + g.dsc, 1, 0, Hcur, E, 0, 1, E, K, e.gru.aw, E, 1, e.gru.ab)) return -1;
+        // LayerNorm weight / bias: column sums over the batch
+        if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1;
+        if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
+    }
+    for (int i = 0; i < L.n_fc; ++i) {
+        const bool last = i == L.n_fc - 1;
+        const float* delta = last ? ws + P.dq : ws + P.dact[i];
+        const int64_t ldd = last ? DQ_LD : L.fc_out[i];
+        const float* in = i == 0 ? ws + P.feats_p : ws + P.act[i - 1];
+        if (jb.add(delta, ldd, 0, in, L.fc_in[i], 0, L.fc_out[i], L.fc_in[i], Bp, L.fc_w[i], L.fc_in[i], 1, L.fc_b[i]))
+            return -1;
+    }
+    MCTSQ_CHECK(jb.part_pos <= P.partial_floats, "internal: partial buffer plan mismatch");
+    MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), st));     // alignment pads stay zero
+    for (int i = 0; i < jb.nlists; ++i)
+        if (launch_wgrad(jb.lists[i], ws + P.partials, st)) return -1;
+    for (int i = 0; i < jb.nlists; ++i)
+        if (launch_wgrad_reduce(jb.lists[i], ws + P.partials, d_grad, st)) return -1;
+    return 0;
+}

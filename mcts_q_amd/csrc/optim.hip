@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 struct AdamArgs {
     float* p; const float* g; float* m; float* v; float* tgt;
     int64_t n;
-    float step_size, bc2_sqrt, b1, b2, eps, max_norm, tau;
+    float step_size, bc2_sqrt, one_m_b1, b2, one_m_b2, eps, max_norm, tau, one_m_tau;
     const double* part;
     float* gnorm_out;
 };
@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void clip_adam_polyak_kernel(AdamArgs a) {
     __syncthreads();
     const float coef = s_coef;
     const int64_t n4 = a.n >> 2;
-    const float one_m_b1 = 1.0f - a.b1, one_m_b2 = 1.0f - a.b2;
-    const float tau = a.tau, one_m_tau = (float)(1.0 - (double)a.tau);
+    // python-float hyper-parameters: 1 - beta is formed in fp64 and THEN rounded, as torch does
+    const float one_m_b1 = a.one_m_b1, one_m_b2 = a.one_m_b2;
+    const float tau = a.tau, one_m_tau = a.one_m_tau;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 p = reinterpret_cast<float4*>(a.p)[i];
         const float4 g4 = reinterpret_cast<const float4*>(a.g)[i];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void clip_adam_polyak_kernel(AdamArgs a) {
             pm[c] = pm[c] + (g - pm[c]) * one_m_b1;                      // exp_avg.lerp_(g, 1-b1)
             pv[c] = __fadd_rn(__fmul_rn(pv[c], a.b2), __fmul_rn(__fmul_rn(g, g), one_m_b2));
             const float denom = sqrtf(pv[c]) / a.bc2_sqrt + a.eps;
-            pp[c] = pp[c] - a.step_size * (pm[c] / denom);
+            pp[c] = pp[c] - __fdiv_rn(__fmul_rn(a.step_size, pm[c]), denom);   // addcdiv_: (value * m) / denom
         }
         reinterpret_cast<float4*>(a.p)[i] = p;
         reinterpret_cast<float4*>(a.m)[i] = m;
@@ -98,8 +99,8 @@ static unsigned stream_grid(int64_t n4) {
 using namespace mctsq;
 
 extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
-                                      float* d_target, int64_t n, int64_t step, float lr, float beta1,
-                                      float beta2, float eps, float max_norm, float tau, float* d_gnorm,
+                                      float* d_target, int64_t n, int64_t step, double lr, double beta1,
+                                      double beta2, double eps, double max_norm, double tau, float* d_gnorm,
                                       void* d_ws, int64_t ws_bytes, void* stream) {
     MCTSQ_CHECK(d_params && d_grad && d_m && d_v, "NULL device pointer");
     MCTSQ_CHECK(n > 0 && n % 16 == 0, "flat buffer length must be a positive multiple of 16 (padded layout)");
@@ -109,24 +110,25 @@ extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, floa
     double* part = (double*)d_ws;
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NPART), dim3(256), 0, st, d_grad, n, part);
     AdamArgs a;
-    a.p = d_params; a.g = d_grad; a.m = d_m; a.v = d_v; a.tgt = tau >= 0.0f ? d_target : nullptr;
+    a.p = d_params; a.g = d_grad; a.m = d_m; a.v = d_v; a.tgt = tau >= 0.0 ? d_target : nullptr;
     a.n = n;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    a.step_size = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    a.step_size = (float)(lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
-    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.max_norm = max_norm; a.tau = tau;
+    a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2);
+    a.eps = (float)eps; a.max_norm = (float)max_norm; a.tau = (float)tau; a.one_m_tau = (float)(1.0 - tau);
     a.part = part; a.gnorm_out = d_gnorm;
-    MCTSQ_CHECK(tau < 0.0f || d_target, "target buffer is NULL but tau >= 0");
+    MCTSQ_CHECK(tau < 0.0 || d_target, "target buffer is NULL but tau >= 0");
     hipLaunchKernelGGL(clip_adam_polyak_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
 
-extern "C" int mctsq_polyak(const float* d_params, float* d_target, int64_t n, float tau, void* stream) {
+extern "C" int mctsq_polyak(const float* d_params, float* d_target, int64_t n, double tau, void* stream) {
     MCTSQ_CHECK(d_params && d_target, "NULL device pointer");
     MCTSQ_CHECK(n > 0 && n % 16 == 0, "flat buffer length must be a positive multiple of 16 (padded layout)");
     hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, d_params,
-                       d_target, n >> 2, tau, (float)(1.0 - (double)tau));
+                       d_target, n >> 2, (float)tau, (float)(1.0 - tau));
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
