@@ -4,13 +4,16 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic input on every rank:
-the batched leaf Q evaluation of BASELINE.json config 2 (gru/gru/gru, 4096 leaf windows per GPU,
-weights from a seeded default init), inputs resident in HBM before the timed region.  Ranks hold
-independent trees/leaves (no data-path collective), so scaling is weak.  Rank 0 prints ONE JSON
-line; `value` is whole-job leaf evaluations per second.  Extra keys report the PER-DQN train-step
-rate (config 3) when the learner path is built, the roofline of the dominant kernel measured with
-HIP events, and the CPU oracle timed on the host cores of the same box.
+One "step" = one pass of the hot path over one batch of synthetic input on every rank: the batched
+leaf Q evaluation of BASELINE.json config 2 (gru/gru/gru, 4096 leaf windows per GPU, seeded
+default-init weights), inputs resident in HBM before the timed region.  Ranks hold independent
+trees/leaves (no data-path collective), so scaling is weak.  Rank 0 prints ONE JSON line; `value`
+is whole-job leaf evaluations per second.
+
+The second half of BASELINE's metric, PER-DQN train steps/s (config 3: 1M-entry replay, batch 1024
+TD updates; data-parallel over ranks with one flat-gradient RCCL all-reduce), is timed in a second
+region and reported under "train".  "roofline" is the dominant kernel of the leaf path timed live
+with HIP events; "cpu_baseline" is the torch-CPU oracle on the host cores of the same box.
 """
 import argparse
 import json
@@ -28,8 +31,8 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f
 HBM_PEAK_GBS = 8000.0
 
 
-def encoder_flops(spec):
-    """Algorithmic forward FLOPs per leaf of the encoder stage and of the head."""
+def forward_flops(spec):
+    """Algorithmic forward FLOPs per leaf: (encoders, head)."""
     enc = 0
     for kind, S, F in zip((spec.price, spec.process, spec.gas), spec.seq, spec.feat_dims):
         if kind == "gru":
@@ -49,38 +52,72 @@ def encoder_flops(spec):
     return enc, head
 
 
-def seeded_state_dict(cfg, seed=3654):
-    """Random-init weights of the configured architecture (DQNModel(seed=3654) equivalent init
-    through the same torch.nn containers; there are no checkpoints to load)."""
+def seeded_net(cfg, seed=3654):
+    """Random-init weights of the configured architecture (same torch.nn containers and seed as
+    DQNModel(seed=3654); there are no checkpoints to load)."""
     from oracle import torch_ref
     torch.manual_seed(seed)
     net = torch_ref.RefQNet(cfg)
     return net, {k: v.detach().numpy() for k, v in net.state_dict().items()}
 
 
-def cpu_baseline(ref_net, B, budget_s=12.0):
-    """Torch-CPU oracle (the arithmetic the reference runs) on the host cores: batched pattern at
-    the GPU's batch size and the as-called pattern (one leaf per call, mcts_per.py:367-370)."""
+def cpu_baseline(cfg, ref_net, B, train_B, budget_s=20.0):
+    """Torch-CPU oracle (the arithmetic the reference runs) on the host cores: batched forwards at
+    the GPU's batch size, the as-called pattern (one leaf per call, mcts_per.py:367-370), and a
+    few full PER-DQN updates at the train batch size."""
+    from oracle import per_numpy, torch_ref
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
     price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
         torch.rand(B, 3, 2, generator=g)
     with torch.no_grad():
         ref_net(price, process, gas)                              # warm-up
-        times, t_end = [], time.perf_counter() + budget_s * 0.6
-        while len(times) < 10 or (time.perf_counter() < t_end and len(times) < 30):
+        times, t_end = [], time.perf_counter() + budget_s * 0.35
+        while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 30):
             t0 = time.perf_counter(); ref_net(price, process, gas); times.append(time.perf_counter() - t0)
         batched = B / float(np.median(times))
         p1, q1, g1 = price[:1], process[:1], gas[:1]
         ref_net(p1, q1, g1)
         n1, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s * 0.3:
+        while time.perf_counter() - t0 < budget_s * 0.15:
             ref_net(p1, q1, g1).max().item(); n1 += 1
         single = n1 / (time.perf_counter() - t0)
+    # train: reference formulation of PER sampling over N priorities + one update, torch CPU
+    N = 100_000
+    rng = np.random.RandomState(3654)
+    prio = np.abs(rng.standard_normal(N))
+    rows, nrows = rng.random_sample((N, 91)).astype(np.float32), rng.random_sample((N, 91)).astype(np.float32)
+    acts, rews = rng.randint(0, 5, N), rng.random_sample(N).astype(np.float32)
+    tgt = torch_ref.RefQNet.from_state_dict(cfg, {k: v.detach().numpy() for k, v in ref_net.state_dict().items()})
+    net = torch_ref.RefQNet.from_state_dict(cfg, {k: v.detach().numpy() for k, v in ref_net.state_dict().items()})
+    m = {k: torch.zeros_like(p) for k, p in net.named_parameters()}
+    v = {k: torch.zeros_like(p) for k, p in net.named_parameters()}
+    tt = []
+    for step in range(1, 4):
+        t0 = time.perf_counter()
+        idx, w = per_numpy.reference_sample(prio, rng.random_sample(train_B))
+        out = torch_ref.dqn_update(net, tgt, m, v, step, (rows[idx], acts[idx], rews[idx], nrows[idx],
+                                                          np.zeros(train_B, np.float32)), w)
+        prio[idx] = out["new_prio"]
+        torch_ref.polyak(net, tgt)
+        tt.append(time.perf_counter() - t0)
+        if sum(tt) > budget_s * 0.5:
+            break
     return {"value": batched, "unit": "leaf evals/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} batched forwards of B={B} (median) + {n1} single-leaf calls; "
-                      "oracle/torch_ref.RefQNet (stock torch CPU ops)",
-            "as_called_b1_evals_per_s": single}
+            "sample": f"{len(times)} batched forwards of B={B} (median) + {n1} single-leaf calls + {len(tt)} "
+                      f"PER-DQN updates of B={train_B} over a {N}-entry buffer; oracle/torch_ref (stock torch CPU "
+                      "ops) + oracle/per_numpy",
+            "as_called_b1_evals_per_s": single, "train_steps_per_s": 1.0 / float(np.median(tt))}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (collected offline with
+    tools/collect_pmc.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -89,17 +126,20 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--train-batch", type=int, default=1024, help="GLOBAL train batch (split over ranks)")
+    ap.add_argument("--replay", type=int, default=1_000_000, help="replay entries per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
@@ -110,7 +150,7 @@ def main():
 
     cfg = dict(price="gru", process="gru", gas="gru", act="relu", flavor="per")
     spec = NetSpec.from_cfg(cfg)
-    ref_net, sd = seeded_state_dict(cfg)
+    ref_net, sd = seeded_net(cfg)
     net = DeviceQNet(spec, dev).load_state_dict(sd)
     B = args.batch
     g = torch.Generator().manual_seed(rank)          # each rank evaluates its own trees' leaves
@@ -120,16 +160,21 @@ def main():
     out = net(price, process, gas)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    for _ in range(args.warmup):
-        net(price, process, gas, out=out)
-    torch.cuda.synchronize()
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # --- timed region: exactly K steps -----------------------------------------------------
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    for _ in range(args.warmup):
+        net(price, process, gas, out=out)
+    # --- timed region: exactly K steps ---------------------------------------------------------
     ev0, ev1 = HipEvent(), HipEvent()
     barrier()
     t0 = time.perf_counter()
@@ -138,29 +183,79 @@ def main():
         net(price, process, gas, out=out)
     ev1.record(stream)
     barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = max_over_ranks(time.perf_counter() - t0)
     gpu_ms_total = ev0.elapsed_ms(ev1)
 
-    # --- dominant kernel (fused GRU encoders) timed live with HIP events, same stream ------
+    # --- dominant kernel (fused GRU encoders + head: the whole forward is one launch) timed live
+    # with HIP events on the launch stream ---------------------------------------------------------
     reps = max(20, min(args.steps, 200))
     evs = [(HipEvent(), HipEvent()) for _ in range(reps)]
     for a, b in evs:
         a.record(stream)
         net(price, process, gas, out=out, mid_event=b.ptr)
     torch.cuda.synchronize()
-    enc_ms = float(np.median([a.elapsed_ms(b) for a, b in evs]))
-    enc_fl, head_fl = encoder_flops(spec)
-    achieved = enc_fl * B / (enc_ms * 1e-3) / 1e12
-    bytes_per_leaf = 91 * 4 + 192 * 4                    # windows in + feature row out (encoder kernel)
+    k_ms = float(np.median([a.elapsed_ms(b) for a, b in evs]))
+    enc_fl, head_fl = forward_flops(spec)
+    flops = (enc_fl + head_fl) * B
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    alg_bytes = (91 * 4 + 5 * 4 + 4 + 4 + 5 * 4) * B             # windows in; Q, vmax, argmax, prior out
     roofline = {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                "kernel": "gru_enc_fwd_kernel<false>", "kernel_ms": enc_ms,
-                "flops_per_launch": enc_fl * B,
-                "hbm_GBs_algorithmic": bytes_per_leaf * B / (enc_ms * 1e-3) / 1e9}
+                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                "kernel": "gru3_head_fwd_kernel<false>", "kernel_ms": k_ms, "flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "hbm_GBs_algorithmic": alg_bytes / (k_ms * 1e-3) / 1e9,
+                "note": "fp32-exact MFMA (v_mfma_f32_16x16x4_f32) path: intensity ~2.5 kFLOP/B, so the "
+                        "fp32 matrix peak bounds it, not HBM"}
+
+    # --- PER-DQN train steps (config 3), data-parallel over ranks ---------------------------------
+    train = None
+    if not args.no_train:
+        from mcts_q_amd.learner import DeviceLearner
+        from mcts_q_amd.per import DevicePER
+        Bt = max(1, args.train_batch // world)
+        N = args.replay
+        L = DeviceLearner(spec, dev, process_group=dist.group.WORLD if world > 1 else None).load_state_dict(sd)
+        buf = DevicePER(N, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(100 + rank)
+        chunk = 250_000
+        for s0 in range(0, N, chunk):
+            k = min(chunk, N - s0)
+            buf.push_rows(torch.rand(k, 91, device=dev, generator=gen),
+                          torch.randint(0, 5, (k,), device=dev, generator=gen),
+                          torch.rand(k, device=dev, generator=gen), torch.rand(k, 91, device=dev, generator=gen),
+                          torch.zeros(k, device=dev))
+        pr = np.abs(np.random.RandomState(3654 + rank).standard_normal(N)).astype(np.float32)
+        pr[: N // 100] = 1.0
+        buf.update_priorities(torch.arange(N, device=dev), torch.from_numpy(pr).to(dev))
+        tsteps = max(10, min(args.steps, 100))
+        twarm = max(3, min(args.warmup, 10))
+        u_all = torch.from_numpy(np.random.RandomState(3654 + rank).random_sample((tsteps + twarm, Bt))).to(dev)
+
+        def train_step(i):
+            idx, phys, w = buf.sample_indices(u_all[i])
+            if world > 1:                        # IS weights are normalised by the GLOBAL max (dqn_per.py:299)
+                wmax_inv = buf.last_local_wmax.clone()
+                dist.all_reduce(wmax_inv, op=dist.ReduceOp.MAX)
+                w = w * (buf.last_local_wmax / wmax_inv).float()
+            batch = buf.gather(phys)
+            abs_td = L.compute_grad(batch, w)
+            L.apply_grad(tau=0.005)
+            buf.update_priorities(idx, abs_td)
+
+        for i in range(twarm):
+            train_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(tsteps):
+            train_step(twarm + i)
+        barrier()
+        twall = max_over_ranks(time.perf_counter() - t0)
+        train = {"metric": "PER-DQN train steps/sec (gru/gru/gru, 1M-entry sum-tree replay per rank, "
+                           f"global batch {Bt * world})", "value": tsteps / twall, "unit": "train steps/s",
+                 "steps": tsteps, "warmup": twarm, "ms_per_step": twall / tsteps * 1e3,
+                 "global_batch": Bt * world, "batch_per_gpu": Bt, "replay_entries_per_gpu": N,
+                 "scaling": "strong (global batch fixed, split over ranks; one flat-gradient all-reduce)",
+                 "transitions_per_s": tsteps * Bt * world / twall, "loss_last": float(L.loss.item())}
 
     if rank == 0:
         res = {
@@ -175,8 +270,10 @@ def main():
             "gpu_ms_per_step_events": gpu_ms_total / args.steps,
             "roofline": roofline,
         }
+        if train is not None:
+            res["train"] = train
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(ref_net, B)
+            res["cpu_baseline"] = cpu_baseline(cfg, ref_net, B, args.train_batch)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

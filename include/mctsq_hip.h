@@ -137,11 +137,13 @@ int mctsq_per_push(uint64_t* d_tree, double* d_prio, const double* d_maxprio, in
 int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, int64_t size,
                           double* d_maxprio, void* d_ws, int64_t ws_bytes, void* stream);
 /* sample (dqn_per.py:283-301): d_u fp64 [B] uniforms in [0,1) -> d_idx int64 [B] LOGICAL
- * indices, d_phys int64 [B] physical slots, d_w fp32 [B] IS weights (N p_i)^-beta / max. */
+ * indices, d_phys int64 [B] physical slots, d_w fp32 [B] IS weights (N p_i)^-beta / max.
+ * d_wmax (optional, fp64 [1]) receives that max before normalisation, so data-parallel ranks can
+ * renormalise by the global maximum. */
 int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
                      int64_t size, const double* d_u, int64_t B, double alpha, double beta,
-                     int64_t* d_idx, int64_t* d_phys, float* d_w, void* d_ws, int64_t ws_bytes,
-                     void* stream);
+                     int64_t* d_idx, int64_t* d_phys, float* d_w, double* d_wmax, void* d_ws,
+                     int64_t ws_bytes, void* stream);
 /* update_priorities (dqn_per.py:307-314): prio[idx[i]] = p[i] sequentially (last duplicate
  * wins); d_idx LOGICAL int64 [B], d_newprio fp32 [B].  d_stamp: int32 [capacity] scratch owned by
  * the buffer, all -1 on entry (the call leaves it all -1 again). */

@@ -169,7 +169,7 @@ int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, 
 
 int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
                      const double* d_u, int64_t B, double alpha, double beta, int64_t* d_idx, int64_t* d_phys,
-                     float* d_w, void* d_ws, int64_t ws_bytes, void* stream) {
+                     float* d_w, double* d_wmax, void* d_ws, int64_t ws_bytes, void* stream) {
     if (check_ring(capacity, head, size)) return -1;
     MCTSQ_CHECK(size >= 1, "cannot sample from an empty buffer");
     MCTSQ_CHECK(B >= 0, "negative batch");
@@ -177,7 +177,7 @@ int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capac
     MCTSQ_CHECK(d_tree && d_prio && d_u && d_idx && d_phys && d_w, "NULL device pointer");
     MCTSQ_CHECK(d_ws && ws_bytes >= B * 8, "workspace too small");
     return launch_per_sample((const unsigned long long*)d_tree, d_prio, capacity, head, size, d_u, B, alpha,
-                             beta, d_idx, d_phys, d_w, (double*)d_ws, (hipStream_t)stream);
+                             beta, d_idx, d_phys, d_w, d_wmax, (double*)d_ws, (hipStream_t)stream);
 }
 
 int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t capacity, int64_t head,

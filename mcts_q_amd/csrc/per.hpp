@@ -28,7 +28,7 @@ struct PerGatherArgs {
 
 int launch_per_sample(const unsigned long long* tree, const double* prio, int64_t cap, int64_t head,
                       int64_t size, const double* u, int64_t B, double alpha, double beta, int64_t* idx,
-                      int64_t* phys, float* w, double* ws_w64, hipStream_t st);
+                      int64_t* phys, float* w, double* wmax, double* ws_w64, hipStream_t st);
 int launch_per_update(unsigned long long* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, const int64_t* idx,
                       const float* newp, int64_t B, double alpha, hipStream_t st);
 int launch_per_push(unsigned long long* tree, double* prio, const double* maxprio, int64_t cap, int64_t head,

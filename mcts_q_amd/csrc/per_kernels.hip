@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const u64* __restrict__
 }
 
 __global__ __launch_bounds__(1024) void per_weight_norm_kernel(const double* __restrict__ w64, int64_t B,
-                                                               float* __restrict__ w) {
+                                                               float* __restrict__ w, double* __restrict__ wmax) {
     __shared__ double red[16];
     double mx = 0.0;
     for (int64_t i = threadIdx.x; i < B; i += 1024) mx = fmax(mx, w64[i]);
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(1024) void per_weight_norm_kernel(const double* __r
     mx = red[0];
     for (int i = 1; i < 16; ++i) mx = fmax(mx, red[i]);
     for (int64_t i = threadIdx.x; i < B; i += 1024) w[i] = (float)(w64[i] / mx);
+    if (wmax && threadIdx.x == 0) *wmax = mx;
 }
 
 // ------------------------------------------------------------------ update / push
@@ -289,13 +290,13 @@ int per_mass_shift(int64_t cap) {
 
 int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                       const double* u, int64_t B, double alpha, double beta, int64_t* idx, int64_t* phys,
-                      float* w, double* ws_w64, hipStream_t st) {
+                      float* w, double* wmax, double* ws_w64, hipStream_t st) {
     PerTree T;
     if (per_tree_desc(cap, &T)) return -1;
     const int shift = per_mass_shift(cap);
     hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, tree, T, prio, cap,
                        head, size, u, B, alpha, beta, shift, idx, phys, ws_w64);
-    hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, ws_w64, B, w);
+    hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, ws_w64, B, w, wmax);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -36,6 +36,7 @@ class DevicePER:
         self.stamp = torch.full((self.capacity,), -1, dtype=torch.int32, device=d)
         self._max_dirty = False
         self._ws = torch.empty(1 << 16, dtype=torch.uint8, device=d)
+        self.last_local_wmax = torch.ones(1, dtype=torch.float64, device=d)   # max IS weight before normalisation
 
     def __len__(self):
         return self.size
@@ -92,8 +93,8 @@ class DevicePER:
         w = torch.empty(B, dtype=torch.float32, device=self.device)
         ws = self._ws_for(B)
         lib.check(lib.mctsq_per_sample(ptr(self.tree), ptr(self.prio), self.capacity, self.head, self.size,
-                                       ptr(u), B, self.alpha, beta, ptr(idx), ptr(phys), ptr(w), ptr(ws),
-                                       ws.numel(), self._st()))
+                                       ptr(u), B, self.alpha, beta, ptr(idx), ptr(phys), ptr(w),
+                                       ptr(self.last_local_wmax), ptr(ws), ws.numel(), self._st()))
         return idx, phys, w
 
     def gather(self, phys):
