@@ -1,6 +1,6 @@
 """Which encoder kinds the loaded libmctsq_hip.so implements (forward / training)."""
-FORWARD_KINDS = ("gru",)
-TRAIN_KINDS = ("gru",)
+FORWARD_KINDS = ("gru", "conv", "mlp")
+TRAIN_KINDS = ("gru", "conv", "mlp")
 
 
 def supported_kinds():

@@ -36,6 +36,38 @@ void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, cons
             fill_gru_slot(ga.slot[ga.nslots++], L.enc[s], params, x[s], s, sv ? &sv[s] : nullptr);
 }
 
+void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
+                    int64_t Bp, float* feats, const SlotSave* sv) {
+    memset(&ca, 0, sizeof(ca));
+    ca.B = B; ca.Bp = Bp; ca.feats = feats;
+    for (int s = 0; s < 2; ++s) {
+        const EncOff& e = L.enc[s];
+        if (e.kind != MCTSQ_ENC_CONV) continue;
+        ConvSlot& c = ca.slot[ca.nslots++];
+        c.x = x[s];
+        c.w1 = params + e.conv.w1; c.b1 = params + e.conv.b1; c.w2 = params + e.conv.w2; c.b2 = params + e.conv.b2;
+        c.aw = params + e.conv.aw; c.ab = params + e.conv.ab; c.lnw = params + e.conv.lnw; c.lnb = params + e.conv.lnb;
+        c.S = e.S; c.Fd = e.Fd; c.F = e.F; c.tf = e.tf; c.out_col = s * E;
+        if (sv) {
+            const SlotSave& v = sv[s];
+            c.sv_h1 = v.c_h1; c.sv_h2 = v.c_h2; c.sv_score = v.score; c.sv_stat = v.stat; c.sv_pool = v.pool;
+            c.sv_x = v.x; c.bw_d2 = v.c_d2; c.bw_d1 = v.c_d1; c.bw_dsc = v.dsc; c.bw_p = v.p;
+        }
+    }
+}
+
+bool fill_mlp_args(MlpArgs& ma, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
+                   int64_t Bp, float* feats, const SlotSave* sv) {
+    memset(&ma, 0, sizeof(ma));
+    const EncOff& e = L.enc[2];
+    if (e.kind != MCTSQ_ENC_MLP) return false;
+    ma.x = x[2];
+    ma.w0 = params + e.mlp.w0; ma.b0 = params + e.mlp.b0; ma.w1 = params + e.mlp.w1; ma.b1 = params + e.mlp.b1;
+    ma.Fd = e.Fd; ma.F = e.F; ma.tf = e.tf; ma.out_col = 2 * E; ma.B = B; ma.Bp = Bp; ma.feats = feats;
+    if (sv) { ma.sv_x = sv[2].m_x; ma.sv_m0 = sv[2].m_m0; ma.bw_d1 = sv[2].m_d1; ma.bw_d0 = sv[2].m_d0; }
+    return true;
+}
+
 // TripleEncoderDQN.forward (dqn_per.py:232-236) + leaf epilogue.  `sv` != NULL keeps the
 // activations the backward pass needs (training) and always takes the per-encoder kernels.
 int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
@@ -43,9 +75,14 @@ int forward_impl(const NetLayout& L, const float* params, const float* const x[3
                  void* ev_encoders_done) {
     GruFwdArgs ga;
     fill_gru_args(ga, L, params, x, B, Bp, feats, sv);
+    ConvFwdArgs ca;
+    fill_conv_args(ca, L, params, x, B, Bp, feats, sv);
+    MlpArgs ma;
+    const bool has_mlp = fill_mlp_args(ma, L, params, x, B, Bp, feats, sv);
     for (int s = 0; s < 3; ++s)
-        MCTSQ_CHECK(L.enc[s].kind == MCTSQ_ENC_GRU, "encoder kind %d is not built into this library yet",
-                    L.enc[s].kind);
+        MCTSQ_CHECK(L.enc[s].kind == MCTSQ_ENC_GRU || L.enc[s].kind == MCTSQ_ENC_CONV ||
+                        L.enc[s].kind == MCTSQ_ENC_MLP,
+                    "encoder kind %d is not built into this library yet", L.enc[s].kind);
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
@@ -64,7 +101,9 @@ int forward_impl(const NetLayout& L, const float* params, const float* const x[3
         if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
         return 0;
     }
+    if (launch_conv_fwd(ca, save, st)) return -1;          // longest kernels first
     if (launch_gru_fwd(ga, save, st)) return -1;
+    if (has_mlp && launch_mlp_fwd(ma, save, st)) return -1;
     if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
     return launch_head_fwd(ha, st);
 }

@@ -1,0 +1,232 @@
+// ConvAttentionEnc (dqn_per.py:21-55) forward and backward.
+//
+// One workgroup (4 waves) = one 16-sample tile of one conv slot.  Rows of every product are the 16
+// samples at ONE time step, so a k=3 convolution is three row-shifted reads of the LDS image
+// [t+1][sample][channel] (zero rows at t = -1 and t = S): conv2 is [16 x 192].[192 x 64] per step
+// on v_mfma_f32_16x16x4_f32 with the wave's 16 output channels of W2 resident in 48 VGPRs.
+// The softmax over time is folded online (one barrier per step), then LayerNorm.
+#include "kernels.hpp"
+#include "learner.hpp"
+#include "pool_core.hpp"
+
+namespace mctsq {
+
+constexpr int CLD = 68;                   // channel row stride of the LDS image (64 + 4)
+
+template <int SMAX>
+struct ConvLds {
+    float img[(SMAX + 2) * TILE * CLD];   // h1 (forward) / delta2 (backward), rows t+1
+    float xs[TILE * ((SMAX + 2) * 8 + 4)];
+    PoolLds pool;
+    PoolBwdLds pb;
+};
+
+template <bool SAVE, int SMAX>
+__global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
+    __shared__ __attribute__((aligned(16))) ConvLds<SMAX> L;
+    constexpr int XLD = (SMAX + 2) * 8 + 4;
+    const int slot = blockIdx.x % args.nslots;
+    const int64_t row0 = (int64_t)(blockIdx.x / args.nslots) * TILE, Bp = args.Bp;
+    const ConvSlot& s = args.slot[slot];
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6, jl = lane & 15, q = lane >> 4;
+    const int j = 16 * wq + jl;
+    const int S = s.S, F = s.F, Fd = s.Fd, FP = F > 4 ? 8 : 4;
+
+    // ---- stage the window (zero rows at both ends) and zero the pad rows of the h1 image ----
+    for (int idx = tid; idx < TILE * (S + 2) * FP; idx += 256) {
+        const int i = idx / ((S + 2) * FP), rem = idx - i * ((S + 2) * FP), tp = rem / FP, f = rem - tp * FP;
+        const int t = tp - 1;
+        float v = 0.0f;
+        if (t >= 0 && t < S && row0 + i < args.B && f < F)
+            v = f < Fd ? s.x[(row0 + i) * (int64_t)(S * Fd) + t * Fd + f] : time_feature(s.tf, t, f - Fd);
+        L.xs[i * XLD + rem] = v;
+        if (SAVE) s.sv_x[((int64_t)tp * Bp + row0 + i) * 8 + f] = v;
+    }
+    if (SAVE && FP == 4)
+        for (int idx = tid; idx < TILE * (S + 2) * 4; idx += 256) {
+            const int i = idx / ((S + 2) * 4), rem = idx - i * ((S + 2) * 4);
+            s.sv_x[((int64_t)(rem >> 2) * Bp + row0 + i) * 8 + 4 + (rem & 3)] = 0.0f;
+        }
+    for (int idx = tid; idx < 2 * TILE * E; idx += 256) {
+        const int e = idx & (TILE * E - 1), i = e >> 6, c = e & 63;
+        const int tp = idx < TILE * E ? 0 : S + 1;
+        L.img[(tp * TILE + i) * CLD + c] = 0.0f;
+        if (SAVE) s.sv_h1[((int64_t)tp * Bp + row0 + i) * E + c] = 0.0f;
+    }
+    // ---- weight fragments ----------------------------------------------------------------------
+    const int nk1 = 3 * FP / 4;                                  // 3 or 6 k-steps for conv1
+    float w1f[6];
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+        const int k = 4 * kk + q, tap = k / FP, f = k - tap * FP;
+        w1f[kk] = (kk < nk1 && f < F) ? s.w1[(int64_t)j * F * 3 + f * 3 + tap] : 0.0f;
+    }
+    float w2f[3][16];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w2f[tap][e] = s.w2[(int64_t)j * (E * 3) + (16 * q + e) * 3 + tap];
+    const float b1j = s.b1[j], b2j = s.b2[j];
+    PoolCore<SAVE> pc;
+    pc.init(s.aw, s.ab, lane, wq);
+    __syncthreads();
+
+    // ---- conv1 + ReLU -> h1 image ----------------------------------------------------------------
+    for (int t = 0; t < S; ++t) {
+        const float* xa = &L.xs[(lane & 15) * XLD + t * FP + q];
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk)
+            if (kk < nk1) acc = mfma16(xa[4 * kk], w1f[kk], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = fmaxf(acc[r] + b1j, 0.0f);
+            L.img[((t + 1) * TILE + 4 * q + r) * CLD + j] = v;
+            if (SAVE) s.sv_h1[((int64_t)(t + 1) * Bp + row0 + 4 * q + r) * E + j] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 + ReLU, attention pooling folded online ---------------------------------------------
+    for (int t = 0; t < S; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        const float4* r0 = reinterpret_cast<const float4*>(&L.img[((t + 0) * TILE + (lane & 15)) * CLD + 16 * q]);
+        const float4* r1 = reinterpret_cast<const float4*>(&L.img[((t + 1) * TILE + (lane & 15)) * CLD + 16 * q]);
+        const float4* r2 = reinterpret_cast<const float4*>(&L.img[((t + 2) * TILE + (lane & 15)) * CLD + 16 * q]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a0 = r0[c], a1 = r1[c], a2 = r2[c];
+            acc0 = mfma16(a0.x, w2f[0][4 * c + 0], acc0); acc1 = mfma16(a1.x, w2f[1][4 * c + 0], acc1); acc2 = mfma16(a2.x, w2f[2][4 * c + 0], acc2);
+            acc0 = mfma16(a0.y, w2f[0][4 * c + 1], acc0); acc1 = mfma16(a1.y, w2f[1][4 * c + 1], acc1); acc2 = mfma16(a2.y, w2f[2][4 * c + 1], acc2);
+            acc0 = mfma16(a0.z, w2f[0][4 * c + 2], acc0); acc1 = mfma16(a1.z, w2f[1][4 * c + 2], acc1); acc2 = mfma16(a2.z, w2f[2][4 * c + 2], acc2);
+            acc0 = mfma16(a0.w, w2f[0][4 * c + 3], acc0); acc1 = mfma16(a1.w, w2f[1][4 * c + 3], acc1); acc2 = mfma16(a2.w, w2f[2][4 * c + 3], acc2);
+        }
+        if (t > 0) pc.attend(L.pool, cur, t - 1, s.sv_score, row0, Bp);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = fmaxf(((acc0[r] + acc1[r]) + acc2[r]) + b2j, 0.0f);
+            if (SAVE) s.sv_h2[((int64_t)t * Bp + row0 + 4 * q + r) * E + j] = v[r];
+        }
+        pc.publish(L.pool, nxt, v);
+        __syncthreads();
+    }
+    pc.attend(L.pool, S & 1, S - 1, s.sv_score, row0, Bp);
+    pc.fin0(L.pool);
+    __syncthreads();
+    pc.fin1(L.pool);
+    __syncthreads();
+    pc.fin2(L.pool, s.lnw, s.lnb, args.feats + row0 * FEAT + s.out_col, FEAT, s.sv_pool, s.sv_stat, row0);
+}
+
+int launch_conv_fwd(const ConvFwdArgs& a, bool save, hipStream_t st) {
+    if (a.nslots == 0 || a.B == 0) return 0;
+    int smax = 0;
+    for (int i = 0; i < a.nslots; ++i) {
+        MCTSQ_CHECK(a.slot[i].S <= 26 && a.slot[i].F <= MAX_F, "conv encoder window %dx%d unsupported (S <= 26)",
+                    a.slot[i].S, a.slot[i].F);
+        smax = a.slot[i].S > smax ? a.slot[i].S : smax;
+    }
+    MCTSQ_CHECK(a.Bp % TILE == 0 && a.Bp >= a.B, "padded batch must be a multiple of %d", TILE);
+    dim3 grid((unsigned)(a.Bp / TILE * a.nslots)), blk(256);
+    if (smax <= 12) {
+        if (save) hipLaunchKernelGGL((conv_enc_fwd_kernel<true, 12>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((conv_enc_fwd_kernel<false, 12>), grid, blk, 0, st, a);
+    } else {
+        if (save) hipLaunchKernelGGL((conv_enc_fwd_kernel<true, 26>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((conv_enc_fwd_kernel<false, 26>), grid, blk, 0, st, a);
+    }
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ======================================================================================= backward
+// dfeat -> LayerNorm/attention backward -> delta2 (pre-activation gradient of conv2, kept in the
+// LDS image and written out) -> delta1 = ReLU'(h1) * (delta2 (*) W2 transposed in time).
+template <int SMAX>
+__global__ __launch_bounds__(256) void conv_enc_bwd_kernel(ConvBwdArgs args) {
+    __shared__ __attribute__((aligned(16))) ConvLds<SMAX> L;
+    const int slot = blockIdx.x % args.nslots;
+    const int64_t row0 = (int64_t)(blockIdx.x / args.nslots) * TILE, Bp = args.Bp;
+    const ConvSlot& s = args.slot[slot];
+    const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6, jl = lane & 15, q = lane >> 4;
+    const int j = 16 * wq + jl;
+    const int S = s.S;
+
+    for (int idx = tid; idx < 2 * TILE * E; idx += 256) {
+        const int e = idx & (TILE * E - 1), i = e >> 6, c = e & 63;
+        L.img[((idx < TILE * E ? 0 : S + 1) * TILE + i) * CLD + c] = 0.0f;
+    }
+    // transposed-conv fragments: B[k = (tap, c)][col = c'] = W2[c][c'][tap], k = tap*64 + 16q + e
+    float wt[3][16];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wt[tap][e] = s.w2[(int64_t)(16 * q + e) * (E * 3) + j * 3 + tap];
+    const float awj = s.aw[j];
+
+    PoolBwdCore pb;
+    pb.prepare(L.pb, args.dfeat, s.out_col, s.lnw, s.sv_stat, s.sv_pool, s.bw_p, lane, wq, row0);
+    for (int t = 0; t < S; ++t) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = s.sv_h2[((int64_t)t * Bp + row0 + 4 * q + r) * E + j];
+        pb.publish_e(L.pb, t, v);
+    }
+    __syncthreads();
+    pb.finish(L.pb);
+    // ---- delta2 ------------------------------------------------------------------------------------
+    for (int t = 0; t < S; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            const int64_t row = (int64_t)t * Bp + row0 + i;
+            float at, dsc;
+            pb.step_terms(L.pb, t, r, s.sv_score[row], at, dsc);
+            if (wq == 0 && jl == 0) s.bw_dsc[row] = dsc;
+            const float h2 = s.sv_h2[row * E + j];
+            const float d2 = h2 > 0.0f ? at * pb.dpool[r] + dsc * awj : 0.0f;
+            s.bw_d2[row * E + j] = d2;
+            L.img[((t + 1) * TILE + i) * CLD + j] = d2;
+        }
+    }
+    __syncthreads();
+    // ---- delta1[t][c'] = ReLU'(h1) * sum_{tap,c} delta2[t - tap + 1][c] W2[c][c'][tap] -------------
+    for (int t = 0; t < S; ++t) {
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        const float4* r0 = reinterpret_cast<const float4*>(&L.img[((t + 2) * TILE + (lane & 15)) * CLD + 16 * q]);   // tap 0
+        const float4* r1 = reinterpret_cast<const float4*>(&L.img[((t + 1) * TILE + (lane & 15)) * CLD + 16 * q]);   // tap 1
+        const float4* r2 = reinterpret_cast<const float4*>(&L.img[((t + 0) * TILE + (lane & 15)) * CLD + 16 * q]);   // tap 2
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a0 = r0[c], a1 = r1[c], a2 = r2[c];
+            acc0 = mfma16(a0.x, wt[0][4 * c + 0], acc0); acc1 = mfma16(a1.x, wt[1][4 * c + 0], acc1); acc2 = mfma16(a2.x, wt[2][4 * c + 0], acc2);
+            acc0 = mfma16(a0.y, wt[0][4 * c + 1], acc0); acc1 = mfma16(a1.y, wt[1][4 * c + 1], acc1); acc2 = mfma16(a2.y, wt[2][4 * c + 1], acc2);
+            acc0 = mfma16(a0.z, wt[0][4 * c + 2], acc0); acc1 = mfma16(a1.z, wt[1][4 * c + 2], acc1); acc2 = mfma16(a2.z, wt[2][4 * c + 2], acc2);
+            acc0 = mfma16(a0.w, wt[0][4 * c + 3], acc0); acc1 = mfma16(a1.w, wt[1][4 * c + 3], acc1); acc2 = mfma16(a2.w, wt[2][4 * c + 3], acc2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = (int64_t)t * Bp + row0 + 4 * q + r;
+            const float h1 = s.sv_h1[(row + Bp) * E + j];                  // block t+1
+            s.bw_d1[row * E + j] = h1 > 0.0f ? (acc0[r] + acc1[r]) + acc2[r] : 0.0f;
+        }
+    }
+}
+
+int launch_conv_bwd(const ConvBwdArgs& a, hipStream_t st) {
+    if (a.nslots == 0) return 0;
+    int smax = 0;
+    for (int i = 0; i < a.nslots; ++i) {
+        MCTSQ_CHECK(a.slot[i].S <= 26, "conv encoder window too long");
+        smax = a.slot[i].S > smax ? a.slot[i].S : smax;
+    }
+    dim3 grid((unsigned)(a.Bp / TILE * a.nslots)), blk(256);
+    if (smax <= 12) hipLaunchKernelGGL((conv_enc_bwd_kernel<12>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv_enc_bwd_kernel<26>), grid, blk, 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mctsq

@@ -7,9 +7,14 @@ namespace mctsq {
 
 // Training-time record of one encoder slot (workspace pointers; fields used depend on the kind).
 struct SlotSave {
+    // shared by the attention-pooled encoders (GRU, conv)
+    float *score, *stat, *pool, *x, *dsc, *p;
     // GRU-attention (kernels.hpp: GruSlot)
-    float *h, *r, *z, *n, *hn, *score, *stat, *pool, *x;
-    float *g, *dsc, *p;
+    float *h, *r, *z, *n, *hn, *g;
+    // Conv-attention (kernels.hpp: ConvSlot)
+    float *c_h1, *c_h2, *c_d2, *c_d1;
+    // gas/EUA MLP (kernels.hpp: MlpArgs)
+    float *m_x, *m_m0, *m_d1, *m_d0;
 };
 
 struct HeadOut {
@@ -20,6 +25,10 @@ struct HeadOut {
 };
 
 void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
+                   int64_t Bp, float* feats, const SlotSave* sv);
+void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
+                    int64_t Bp, float* feats, const SlotSave* sv);
+bool fill_mlp_args(MlpArgs& ma, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
                    int64_t Bp, float* feats, const SlotSave* sv);
 int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
                  float* feats, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,

@@ -29,6 +29,45 @@ struct GruFwdArgs {
 };
 int launch_gru_fwd(const GruFwdArgs& args, bool save, hipStream_t st);
 
+// ---------------- Conv-attention encoder (dqn_per.py:21-55) ----------------
+struct ConvSlot {
+    const float* x;                      // [B][S][Fd]
+    const float *w1, *b1, *w2, *b2, *aw, *ab, *lnw, *lnb;
+    int S, Fd, F, tf, out_col;
+    // training record (NULL for inference)
+    float* sv_h1;                        // [S+2][Bp][64] post-ReLU conv1, zero blocks at both ends
+    float* sv_h2;                        // [S][Bp][64] post-ReLU conv2
+    float* sv_score;                     // [S][Bp], log2 units
+    float* sv_stat;                      // [Bp][4] = max, sum, LN mean, LN rstd
+    float* sv_pool;                      // [Bp][64]
+    float* sv_x;                         // [S+2][Bp][8] time-major window, zero blocks at both ends
+    // backward outputs
+    float *bw_d2, *bw_d1;                // [S][Bp][64] d(pre-activation) of conv2 / conv1
+    float* bw_dsc;                       // [S][Bp]
+    float* bw_p;                         // [Bp][64]
+};
+struct ConvFwdArgs {
+    ConvSlot slot[2];
+    int nslots;
+    int64_t B, Bp;
+    float* feats;                        // [Bp][192]
+};
+int launch_conv_fwd(const ConvFwdArgs& args, bool save, hipStream_t st);
+
+// ---------------- gas/EUA MLP encoder (dqn_per.py:108-114, 128-130) ----------------
+struct MlpArgs {
+    const float* x;                      // [B][3*Fd]
+    const float *w0, *b0, *w1, *b1;
+    int Fd, F, tf, out_col;              // F = Fd (+2 time features per step)
+    int64_t B, Bp;
+    float* feats;                        // [Bp][192]
+    float* sv_x;                         // [Bp][16] flattened window incl. time features, zero padded
+    float* sv_m0;                        // [Bp][64] post-ReLU hidden layer
+    float *bw_d1, *bw_d0;                // [Bp][64] d(pre-activation) of layer 1 / layer 0
+    const float* dfeat;                  // backward input [Bp][192]
+};
+int launch_mlp_fwd(const MlpArgs& a, bool save, hipStream_t st);
+
 // ---------------- head ----------------
 struct HeadArgs {
     const float* feats;                  // [Bp][192]

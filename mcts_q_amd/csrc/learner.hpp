@@ -43,6 +43,16 @@ struct GruBwdArgs {
 };
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
 
+// ---- Conv-attention backward (enc_conv.hip) and gas/EUA MLP backward (enc_mlp.hip) ----
+struct ConvBwdArgs {
+    ConvSlot slot[2];
+    int nslots;
+    int64_t Bp;
+    const float* dfeat;         // [Bp][192]
+};
+int launch_conv_bwd(const ConvBwdArgs& a, hipStream_t st);
+int launch_mlp_bwd(const MlpArgs& a, hipStream_t st);
+
 // ---- weight gradients: dW[m][n] = sum_k A[k][m] * Bm[k][n], bias[m] = sum_k A[k][m] ----
 // Split over K into `nsplit` chunks whose partial results are reduced in a fixed order, so the
 // gradient is bitwise reproducible (no float atomics).

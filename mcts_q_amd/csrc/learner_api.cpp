@@ -20,13 +20,18 @@ struct Carver {
     }
 };
 
-struct GruPlan { int64_t h, r, z, n, hn, score, stat, pool, x, g, dsc, p; };
+struct SlotPlan {                      // float offsets; which fields are used depends on the kind
+    int64_t score, stat, pool, x, dsc, p;
+    int64_t h, r, z, n, hn, g;          // gru
+    int64_t c_h1, c_h2, c_d2, c_d1;     // conv
+    int64_t m_x, m_m0, m_d1, m_d0;      // mlp
+};
 
 struct TrainPlan {
     int64_t Bp;
     int64_t feats_t, q_t, qnext, feats_p, q_p, dq, dfeat;
     int64_t act[4], dact[4];
-    GruPlan gru[3];
+    SlotPlan slot[3];
     int64_t partials, partial_floats;
     int64_t total;                                       // floats
 };
@@ -56,16 +61,27 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
     int64_t pf = 0;
     for (int s = 0; s < 3; ++s) {
         const EncOff& e = L.enc[s];
-        const int64_t S = e.S;
-        MCTSQ_CHECK(e.kind == MCTSQ_ENC_GRU, "training path: encoder kind %d is not built into this library yet", e.kind);
-        GruPlan& g = P->gru[s];
-        g.h = c.take((S + 1) * Bp * E);
-        g.r = c.take(S * Bp * E); g.z = c.take(S * Bp * E); g.n = c.take(S * Bp * E); g.hn = c.take(S * Bp * E);
-        g.score = c.take(S * Bp); g.stat = c.take(Bp * 4); g.pool = c.take(Bp * E); g.x = c.take(S * Bp * 8);
-        g.g = c.take(S * Bp * 256); g.dsc = c.take(S * Bp); g.p = c.take(Bp * E);
-        const int64_t K = S * Bp;
-        pf += job_partial_floats(G3, e.F, K) + job_partial_floats(128, E, K) + job_partial_floats(E, E, K) +
-              job_partial_floats(1, E, K) + 2 * job_partial_floats(E, 0, Bp);
+        const int64_t S = e.S, K = S * Bp;
+        SlotPlan& g = P->slot[s];
+        if (e.kind == MCTSQ_ENC_GRU) {
+            g.h = c.take((S + 1) * Bp * E);
+            g.r = c.take(K * E); g.z = c.take(K * E); g.n = c.take(K * E); g.hn = c.take(K * E);
+            g.score = c.take(K); g.stat = c.take(Bp * 4); g.pool = c.take(Bp * E); g.x = c.take(K * 8);
+            g.g = c.take(K * 256); g.dsc = c.take(K); g.p = c.take(Bp * E);
+            pf += job_partial_floats(G3, e.F, K) + job_partial_floats(128, E, K) + job_partial_floats(E, E, K) +
+                  job_partial_floats(1, E, K) + 2 * job_partial_floats(E, 0, Bp);
+        } else if (e.kind == MCTSQ_ENC_CONV) {
+            g.c_h1 = c.take((S + 2) * Bp * E); g.c_h2 = c.take(K * E);
+            g.score = c.take(K); g.stat = c.take(Bp * 4); g.pool = c.take(Bp * E); g.x = c.take((S + 2) * Bp * 8);
+            g.c_d2 = c.take(K * E); g.c_d1 = c.take(K * E); g.dsc = c.take(K); g.p = c.take(Bp * E);
+            pf += 3 * job_partial_floats(E, E, K) + 3 * job_partial_floats(E, e.F, K) + job_partial_floats(1, E, K) +
+                  2 * job_partial_floats(E, 0, Bp);
+        } else if (e.kind == MCTSQ_ENC_MLP) {
+            g.m_x = c.take(Bp * 16); g.m_m0 = c.take(Bp * E); g.m_d1 = c.take(Bp * E); g.m_d0 = c.take(Bp * E);
+            pf += job_partial_floats(E, 3 * e.F, Bp) + job_partial_floats(E, E, Bp);
+        } else {
+            MCTSQ_CHECK(false, "training path: encoder kind %d is not built into this library yet", e.kind);
+        }
     }
     for (int i = 0; i < L.n_fc; ++i) pf += job_partial_floats(L.fc_out[i], L.fc_in[i], Bp);
     P->partial_floats = pf;
@@ -146,10 +162,13 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     SlotSave sv[3];
     memset(sv, 0, sizeof(sv));
     for (int s = 0; s < 3; ++s) {
-        const GruPlan& g = P.gru[s];
-        sv[s].h = ws + g.h; sv[s].r = ws + g.r; sv[s].z = ws + g.z; sv[s].n = ws + g.n; sv[s].hn = ws + g.hn;
-        sv[s].score = ws + g.score; sv[s].stat = ws + g.stat; sv[s].pool = ws + g.pool; sv[s].x = ws + g.x;
-        sv[s].g = ws + g.g; sv[s].dsc = ws + g.dsc; sv[s].p = ws + g.p;
+        const SlotPlan& g = P.slot[s];
+        SlotSave& v = sv[s];
+        v.score = ws + g.score; v.stat = ws + g.stat; v.pool = ws + g.pool; v.x = ws + g.x; v.dsc = ws + g.dsc;
+        v.p = ws + g.p;
+        v.h = ws + g.h; v.r = ws + g.r; v.z = ws + g.z; v.n = ws + g.n; v.hn = ws + g.hn; v.g = ws + g.g;
+        v.c_h1 = ws + g.c_h1; v.c_h2 = ws + g.c_h2; v.c_d2 = ws + g.c_d2; v.c_d1 = ws + g.c_d1;
+        v.m_x = ws + g.m_x; v.m_m0 = ws + g.m_m0; v.m_d1 = ws + g.m_d1; v.m_d0 = ws + g.m_d0;
     }
     float* sv_act[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i + 1 < L.n_fc; ++i) sv_act[i] = ws + P.act[i];
@@ -178,6 +197,13 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     }
     // 5. encoder backward (deltas)
     {
+        ConvFwdArgs ca;
+        fill_conv_args(ca, L, d_params, xs, B, Bp, ws + P.feats_p, sv);
+        ConvBwdArgs cb;
+        memset(&cb, 0, sizeof(cb));
+        cb.nslots = ca.nslots; cb.Bp = Bp; cb.dfeat = ws + P.dfeat;
+        for (int i = 0; i < ca.nslots; ++i) cb.slot[i] = ca.slot[i];
+        if (launch_conv_bwd(cb, st)) return -1;
         GruFwdArgs ga;
         fill_gru_args(ga, L, d_params, xs, B, Bp, ws + P.feats_p, sv);
         GruBwdArgs gb;
@@ -185,27 +211,49 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         gb.nslots = ga.nslots; gb.Bp = Bp; gb.dfeat = ws + P.dfeat;
         for (int i = 0; i < ga.nslots; ++i) gb.slot[i] = ga.slot[i];
         if (launch_gru_bwd(gb, st)) return -1;
+        MlpArgs ma;
+        if (fill_mlp_args(ma, L, d_params, xs, B, Bp, ws + P.feats_p, sv)) {
+            ma.dfeat = ws + P.dfeat;
+            if (launch_mlp_bwd(ma, st)) return -1;
+        }
     }
     // 6. weight gradients: every tensor is one (or a few) K-contractions
     JobBuilder jb;
     for (int s = 0; s < 3; ++s) {
         const EncOff& e = L.enc[s];
-        const GruPlan& g = P.gru[s];
+        const SlotPlan& g = P.slot[s];
         const int64_t K = (int64_t)e.S * Bp;
-        const float* G = ws + g.g;
-        const float* Hprev = ws + g.h;                    // block t = h_{t-1}
-        const float* Hcur = ws + g.h + Bp * E;            // block t+1 = h_t
-        // W_ih [192][F] + b_ih: delta (r|z|n) x x_t
-        if (jb.add(G, 256, 0, ws + g.x, 8, 0, G3, e.F, K, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
-        // W_hh rows r,z + b_hh[0:128]: delta (r|z) x h_{t-1}
-        if (jb.add(G, 256, 0, Hprev, E, 0, 2 * E, E, K, e.gru.whh, E, 1, e.gru.bhh)) return -1;
-        // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1}
-        if (jb.add(G, 256, 3 * E, Hprev, E, 0, E, E, K, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E)) return -1;
-        // attention score Linear(64,1): d(score) x h_t
-        if (jb.add(ws + g.dsc, 1, 0, Hcur, E, 0, 1, E, K, e.gru.aw, E, 1, e.gru.ab)) return -1;
-        // LayerNorm weight / bias: column sums over the batch
-        if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1;
-        if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
+        if (e.kind == MCTSQ_ENC_GRU) {
+            const float* G = ws + g.g;
+            const float* Hprev = ws + g.h;                    // block t = h_{t-1}
+            const float* Hcur = ws + g.h + Bp * E;            // block t+1 = h_t
+            // W_ih [192][F] + b_ih: delta (r|z|n) x x_t
+            if (jb.add(G, 256, 0, ws + g.x, 8, 0, G3, e.F, K, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
+            // W_hh rows r,z + b_hh[0:128]: delta (r|z) x h_{t-1}
+            if (jb.add(G, 256, 0, Hprev, E, 0, 2 * E, E, K, e.gru.whh, E, 1, e.gru.bhh)) return -1;
+            // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1}
+            if (jb.add(G, 256, 3 * E, Hprev, E, 0, E, E, K, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E)) return -1;
+            // attention score Linear(64,1): d(score) x h_t
+            if (jb.add(ws + g.dsc, 1, 0, Hcur, E, 0, 1, E, K, e.gru.aw, E, 1, e.gru.ab)) return -1;
+            // LayerNorm weight / bias: column sums over the batch
+            if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1;
+            if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
+        } else if (e.kind == MCTSQ_ENC_CONV) {
+            // conv weights [out][in][3]: one contraction per tap against the time-shifted input
+            // (zero blocks at both ends of the saved images implement the padding)
+            for (int tap = 0; tap < 3; ++tap) {
+                if (jb.add(ws + g.c_d2, E, 0, ws + g.c_h1 + (int64_t)tap * Bp * E, E, 0, E, E, K, e.conv.w2 + tap, 3 * E,
+                           3, tap == 0 ? e.conv.b2 : -1)) return -1;
+                if (jb.add(ws + g.c_d1, E, 0, ws + g.x + (int64_t)tap * Bp * 8, 8, 0, E, e.F, K, e.conv.w1 + tap,
+                           3 * e.F, 3, tap == 0 ? e.conv.b1 : -1)) return -1;
+            }
+            if (jb.add(ws + g.dsc, 1, 0, ws + g.c_h2, E, 0, 1, E, K, e.conv.aw, E, 1, e.conv.ab)) return -1;
+            if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnw)) return -1;
+            if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnb)) return -1;
+        } else {    // mlp
+            if (jb.add(ws + g.m_d0, E, 0, ws + g.m_x, 16, 0, E, 3 * e.F, Bp, e.mlp.w0, 3 * e.F, 1, e.mlp.b0)) return -1;
+            if (jb.add(ws + g.m_d1, E, 0, ws + g.m_m0, E, 0, E, E, Bp, e.mlp.w1, E, 1, e.mlp.b1)) return -1;
+        }
     }
     for (int i = 0; i < L.n_fc; ++i) {
         const bool last = i == L.n_fc - 1;

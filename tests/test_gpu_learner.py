@@ -153,12 +153,14 @@ def test_clip_adam_polyak_matches_torch():
         np.testing.assert_allclose(t.cpu().numpy(), rt.numpy(), rtol=2.4e-7, atol=2e-7)
 
 
+@pytest.mark.parametrize("combo", ["gru/gru/gru", "conv/conv/mlp", "gru/conv/gru"])
 @pytest.mark.parametrize("B", [5, 1024])
-def test_gradient_matches_torch_autograd_batched(B):
+def test_gradient_matches_torch_autograd_batched(B, combo):
     """Ragged and BASELINE config-3 batch sizes vs autograd of the torch oracle, real target path."""
     from mcts_q_amd import NetSpec
     from mcts_q_amd.learner import DeviceLearner
-    cfg = dict(price="gru", process="gru", gas="gru", act="relu", flavor="per")
+    pe, pr, ga = combo.split("/")
+    cfg = dict(price=pe, process=pr, gas=ga, act="relu", flavor="per")
     torch.manual_seed(7)
     net, tgt = torch_ref.RefQNet(cfg), torch_ref.RefQNet(cfg)
     spec = NetSpec.from_cfg(cfg)

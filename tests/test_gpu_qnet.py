@@ -54,7 +54,8 @@ def test_forward_matches_reference_golden(path):
 
 
 @pytest.mark.parametrize("B", [1, 3, 4, 17, 4096])
-@pytest.mark.parametrize("combo", [("gru", "gru", "gru")])
+@pytest.mark.parametrize("combo", [("gru", "gru", "gru"), ("conv", "conv", "mlp"), ("conv", "gru", "mlp"),
+                                   ("gru", "conv", "gru")])
 def test_forward_matches_oracle_batched(combo, B):
     """Ragged (non multiple of 16), single-leaf and the BASELINE config-2 batch."""
     from mcts_q_amd import NetSpec
