@@ -1,5 +1,5 @@
 """Which encoder kinds the loaded libmctsq_hip.so implements (forward / training)."""
-FORWARD_KINDS = ("gru", "conv", "mlp")
+FORWARD_KINDS = ("gru", "conv", "mlp", "transformer")
 TRAIN_KINDS = ("gru", "conv", "mlp")
 
 

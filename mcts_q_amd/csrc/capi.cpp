@@ -68,21 +68,45 @@ bool fill_mlp_args(MlpArgs& ma, const NetLayout& L, const float* params, const f
     return true;
 }
 
+int64_t forward_ws_floats(const NetLayout& L, int64_t Bp) {
+    int64_t n = Bp * FEAT;
+    for (int s = 0; s < 2; ++s)
+        if (L.enc[s].kind == MCTSQ_ENC_TRANSFORMER) n += 2 * tf_padded_tokens(Bp, L.enc[s].S) * E;
+    return n;
+}
+
+static void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
+                         int64_t Bp, float* feats, float* hbuf) {
+    memset(&t, 0, sizeof(t));
+    t.x = x;
+    t.pos = params + e.tfm.pos; t.ew = params + e.tfm.ew; t.eb = params + e.tfm.eb;
+    for (int l = 0; l < 2; ++l) {
+        const TfLayerOff& o = e.tfm.layer[l];
+        TfLayerW& w = t.layer[l];
+        w.inw = params + o.inw; w.inb = params + o.inb; w.ow = params + o.ow; w.ob = params + o.ob;
+        w.l1w = params + o.l1w; w.l1b = params + o.l1b; w.l2w = params + o.l2w; w.l2b = params + o.l2b;
+        w.n1w = params + o.n1w; w.n1b = params + o.n1b; w.n2w = params + o.n2w; w.n2b = params + o.n2b;
+    }
+    t.lnw = params + e.tfm.lnw; t.lnb = params + e.tfm.lnb;
+    t.S = e.S; t.Fd = e.Fd; t.F = e.F; t.tf = e.tf; t.out_col = slot * E; t.NS = 128 / e.S;
+    t.B = B; t.Bp = Bp; t.T = B * e.S; t.Tp = tf_padded_tokens(Bp, e.S);
+    t.h0 = hbuf; t.h1 = hbuf + t.Tp * E; t.feats = feats;
+}
+
 // TripleEncoderDQN.forward (dqn_per.py:232-236) + leaf epilogue.  `sv` != NULL keeps the
 // activations the backward pass needs (training) and always takes the per-encoder kernels.
 int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
-                 float* feats, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
+                 float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
                  void* ev_encoders_done) {
+    float* feats = ws;
     GruFwdArgs ga;
     fill_gru_args(ga, L, params, x, B, Bp, feats, sv);
     ConvFwdArgs ca;
     fill_conv_args(ca, L, params, x, B, Bp, feats, sv);
     MlpArgs ma;
     const bool has_mlp = fill_mlp_args(ma, L, params, x, B, Bp, feats, sv);
-    for (int s = 0; s < 3; ++s)
-        MCTSQ_CHECK(L.enc[s].kind == MCTSQ_ENC_GRU || L.enc[s].kind == MCTSQ_ENC_CONV ||
-                        L.enc[s].kind == MCTSQ_ENC_MLP,
-                    "encoder kind %d is not built into this library yet", L.enc[s].kind);
+    const bool has_tf = L.enc[0].kind == MCTSQ_ENC_TRANSFORMER || L.enc[1].kind == MCTSQ_ENC_TRANSFORMER;
+    MCTSQ_CHECK(!(has_tf && sv), "training path: the transformer encoder is not built into this library yet");
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
@@ -100,6 +124,16 @@ int forward_impl(const NetLayout& L, const float* params, const float* const x[3
         if (launch_gru3_head_fwd(ga, ha, false, st)) return -1;
         if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
         return 0;
+    }
+    {
+        float* hbuf = ws + Bp * FEAT;
+        for (int s = 0; s < 2; ++s) {
+            if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
+            TfArgs t;
+            fill_tf_args(t, L.enc[s], params, x[s], s, B, Bp, feats, hbuf);
+            if (launch_tf_fwd(t, st)) return -1;
+            hbuf += 2 * t.Tp * E;
+        }
     }
     if (launch_conv_fwd(ca, save, st)) return -1;          // longest kernels first
     if (launch_gru_fwd(ga, save, st)) return -1;
@@ -138,7 +172,7 @@ int64_t mctsq_q_forward_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
     if (build_layout(net, &L)) return -1;
     if (B < 0) { set_error("negative batch"); return -1; }
     const int64_t Bp = round_up(B > 0 ? B : 1, TILE);
-    return Bp * FEAT * (int64_t)sizeof(float);
+    return forward_ws_floats(L, Bp) * (int64_t)sizeof(float);
 }
 
 int mctsq_q_forward(const mctsq_net_desc* net, const float* d_params, const float* d_price,
@@ -158,8 +192,9 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
     if (B == 0) return 0;
     MCTSQ_CHECK(d_params && d_price && d_process && d_gas && d_q, "NULL device pointer");
     const int64_t Bp = round_up(B, TILE);
-    MCTSQ_CHECK(d_ws && ws_bytes >= Bp * FEAT * (int64_t)sizeof(float), "workspace too small (%lld bytes)",
-                (long long)ws_bytes);
+    MCTSQ_CHECK(d_ws && ws_bytes >= forward_ws_floats(L, Bp) * (int64_t)sizeof(float),
+                "workspace too small (%lld bytes)", (long long)ws_bytes);
+    MCTSQ_CHECK(((uintptr_t)d_ws & 15) == 0, "workspace must be 16-byte aligned");
     const float* x[3] = {d_price, d_process, d_gas};
     HeadOut out{d_q, d_vmax, d_argmax, d_prior};
     return forward_impl(L, d_params, x, B, Bp, (float*)d_ws, out, nullptr, nullptr, (hipStream_t)stream,

@@ -1,0 +1,319 @@
+// TransformerEnc (dqn_per.py:80-101) forward: Linear embed + learned positional table, two post-LN
+// nn.TransformerEncoderLayer(d=64, 4 heads, ff=2048, ReLU, dropout off), mean over time, LayerNorm.
+//
+// Tokens are rows: token = sample*S + t, activations [tokens][64] fp32 in HBM between the stages
+//   embed -> { attention block -> FFN block } x 2 -> mean-pool + LayerNorm.
+// The FFN (94 % of the FLOPs) is the MFMA kernel that matters: each wave owns 64 tokens and walks
+// the 2048 hidden units 16 at a time; the hidden tile never leaves registers, because the D layout
+// of the first product (u^T = W1 . h^T: rows = hidden units, columns = tokens) is exactly the
+// A operand the second product (out = u . W2^T) wants.  Weight fragments stream from L2 (the two
+// FFN matrices are 1 MB per layer), activations never touch LDS.
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace mctsq {
+
+constexpr int FF = 2048;
+constexpr int TOK_PER_WAVE = 64;
+constexpr int TOK_PER_WG = 256;
+
+// -------------------------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void tf_embed_kernel(TfArgs a) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tok = gid >> 6;
+    const int c = (int)(gid & 63);
+    if (tok >= a.Tp) return;
+    float v = 0.0f;
+    if (tok < a.T) {
+        const int64_t b = tok / a.S;
+        const int t = (int)(tok - b * a.S);
+        v = a.eb[c];
+        for (int f = 0; f < a.F; ++f) {
+            const float x = f < a.Fd ? a.x[tok * a.Fd + f] : time_feature(a.tf, t, f - a.Fd);
+            v = fmaf(x, a.ew[c * a.F + f], v);
+        }
+        v += a.pos[t * E + c];
+    }
+    a.h0[tok * E + c] = v;
+}
+
+// LayerNorm over the 64 columns of rows held in the MFMA D layout: x[c][r] is column 16c + jl of
+// row 4q + r; the reduction runs over c (registers) and the 16 lanes of the row group.
+__device__ __forceinline__ void ln_rows(float x[4][4], const float* lnw, const float* lnb, int jl) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float mean = row16_sum((x[0][r] + x[1][r]) + (x[2][r] + x[3][r])) * (1.0f / E);
+        float d[4], ss = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { d[c] = x[c][r] - mean; ss += d[c] * d[c]; }
+        const float rstd = 1.0f / sqrtf(row16_sum(ss) * (1.0f / E) + LN_EPS);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c][r] = d[c] * rstd * lnw[16 * c + jl] + lnb[16 * c + jl];
+    }
+}
+
+// ------------------------------------------------------------------------------ attention block
+// One workgroup = NS whole samples (NS*S <= 128 token rows).  h -> in_proj (q|k|v) -> per (sample,
+// head) softmax(q k^T / 4) v -> out_proj -> + h -> LayerNorm1.
+constexpr int AHLD = 68, QLD = 196, AROWS = 128;
+
+__global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
+    __shared__ __attribute__((aligned(16))) float hs[AROWS * AHLD];
+    __shared__ __attribute__((aligned(16))) float qkv[AROWS * QLD];
+    const TfLayerW& W = a.layer[layer];
+    const float* hin = a.h0;                              // ping-pong: h0 -> (attn) h1 -> (ffn) h0
+    float* hout = a.h1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
+    const int S = a.S, NS = a.NS;
+    const int64_t sample0 = (int64_t)blockIdx.x * NS;
+    const int ns = (int)min((int64_t)NS, a.B - sample0);
+    const int rows = ns * S;
+    const int64_t tok0 = sample0 * S;
+
+    for (int idx = tid; idx < AROWS * 16; idx += 256) {
+        const int r = idx >> 4, c4 = idx & 15;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (r < rows) v = reinterpret_cast<const float4*>(hin + (tok0 + r) * E)[c4];
+        *reinterpret_cast<float4*>(&hs[r * AHLD + 4 * c4]) = v;
+    }
+    __syncthreads();
+    // ---- in_proj: [128 x 64] . W_in^T [64 x 192]; wave w owns row tiles 2w, 2w+1 --------------
+    {
+        float af[2][16];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const float4* p = reinterpret_cast<const float4*>(&hs[(32 * w + 16 * mt + jl) * AHLD + 16 * q]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float4 v = p[c]; af[mt][4 * c] = v.x; af[mt][4 * c + 1] = v.y; af[mt][4 * c + 2] = v.z; af[mt][4 * c + 3] = v.w; }
+        }
+        for (int nt = 0; nt < 12; ++nt) {
+            const float4* p = reinterpret_cast<const float4*>(W.inw + (int64_t)(16 * nt + jl) * E + 16 * q);
+            float bf[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float4 v = p[c]; bf[4 * c] = v.x; bf[4 * c + 1] = v.y; bf[4 * c + 2] = v.z; bf[4 * c + 3] = v.w; }
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0 = mfma16(af[0][e], bf[e], acc0); acc1 = mfma16(af[1][e], bf[e], acc1); }
+            const float bias = W.inb[16 * nt + jl];
+            const float sc = nt < 4 ? 0.25f : 1.0f;                  // q / sqrt(head_dim)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                qkv[(32 * w + 4 * q + r) * QLD + 16 * nt + jl] = (acc0[r] + bias) * sc;
+                qkv[(32 * w + 16 + 4 * q + r) * QLD + 16 * nt + jl] = (acc1[r] + bias) * sc;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- attention: one wave per (sample, head) ------------------------------------------------
+    const int nt16 = (S + 15) >> 4;                                 // key / query tiles per sample (1 or 2)
+    for (int p = w; p < ns * 4; p += 4) {
+        const int si = p >> 2, hh = p & 3, rb = si * S;
+        for (int qt = 0; qt < nt16; ++qt) {
+            const int qrow = min(rb + 16 * qt + jl, AROWS - 1);
+            const float4 qv = *reinterpret_cast<const float4*>(&qkv[qrow * QLD + 16 * hh + 4 * q]);
+            f32x4 st[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                st[kt] = (f32x4){0, 0, 0, 0};
+                if (kt < nt16) {
+                    const int krow = min(rb + 16 * kt + jl, AROWS - 1);
+                    const float4 kv = *reinterpret_cast<const float4*>(&qkv[krow * QLD + E + 16 * hh + 4 * q]);
+                    st[kt] = mfma16(kv.x, qv.x, st[kt]); st[kt] = mfma16(kv.y, qv.y, st[kt]);
+                    st[kt] = mfma16(kv.z, qv.z, st[kt]); st[kt] = mfma16(kv.w, qv.w, st[kt]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                    // row = key 16kt + 4q + r, column = query jl
+                        if (16 * kt + 4 * q + r >= S) st[kt][r] = -INFINITY;
+                        mx = fmaxf(mx, st[kt][r]);
+                    }
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = kt < nt16 ? expf(st[kt][r] - mx) : 0.0f;
+                    st[kt][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            // ctx^T[d][query] = sum_key V[key][d] P[key][query]: A lane (d = jl, q) at step r holds V[16kt+4q+r][d]
+            f32x4 ct = {0, 0, 0, 0};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                if (kt < nt16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int vrow = min(rb + 16 * kt + 4 * q + r, AROWS - 1);
+                        ct = mfma16(qkv[vrow * QLD + 2 * E + 16 * hh + jl], st[kt][r] * inv, ct);
+                    }
+                }
+            }
+            // D: ctx^T[d = 4q + r][query = jl] -> the (dead) q slot of this query row
+            if (16 * qt + jl < S)
+                *reinterpret_cast<float4*>(&qkv[(rb + 16 * qt + jl) * QLD + 16 * hh + 4 * q]) =
+                    make_float4(ct[0], ct[1], ct[2], ct[3]);
+        }
+    }
+    __syncthreads();
+    // ---- out_proj + residual + LayerNorm1 --------------------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int rbase = 32 * w + 16 * mt;
+        const float4* p = reinterpret_cast<const float4*>(&qkv[(rbase + jl) * QLD + 16 * q]);
+        float af[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float4 v = p[c]; af[4 * c] = v.x; af[4 * c + 1] = v.y; af[4 * c + 2] = v.z; af[4 * c + 3] = v.w; }
+        float x[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4* wp = reinterpret_cast<const float4*>(W.ow + (int64_t)(16 * c + jl) * E + 16 * q);
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = wp[g];
+                acc = mfma16(af[4 * g], v.x, acc); acc = mfma16(af[4 * g + 1], v.y, acc);
+                acc = mfma16(af[4 * g + 2], v.z, acc); acc = mfma16(af[4 * g + 3], v.w, acc);
+            }
+            const float bias = W.ob[16 * c + jl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[c][r] = (acc[r] + bias) + hs[(rbase + 4 * q + r) * AHLD + 16 * c + jl];
+        }
+        ln_rows(x, W.n1w, W.n1b, jl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rbase + 4 * q + r;
+            if (row < rows) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hout[(tok0 + row) * E + 16 * c + jl] = x[c][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ FFN block
+// hout = LayerNorm2(hin + W2 relu(W1 hin + b1) + b2).  One wave = 64 tokens (4 tiles of 16).
+__global__ __launch_bounds__(256) void tf_ffn_kernel(TfArgs a, int layer) {
+    const TfLayerW& W = a.layer[layer];
+    const float* hin = a.h1;
+    float* hout = a.h0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jl = lane & 15, q = lane >> 4;
+    const int64_t tok0 = ((int64_t)blockIdx.x * 4 + w) * TOK_PER_WAVE;
+    if (tok0 >= a.T) return;
+    // B operand of the first product: h^T, lane (token jl, k group q) holds h[token][16q .. 16q+15]
+    float hf[4][16];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + 16 * tt + jl) * E + 16 * q);   // rows < Tp
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float4 v = p[c]; hf[tt][4 * c] = v.x; hf[tt][4 * c + 1] = v.y; hf[tt][4 * c + 2] = v.z; hf[tt][4 * c + 3] = v.w; }
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[tt][c] = (f32x4){0, 0, 0, 0};
+
+    const float4* w1p = reinterpret_cast<const float4*>(W.l1w + (int64_t)jl * E + 16 * q);        // + nt * 16 rows
+    const float* w2p = W.l2w + (int64_t)jl * FF + 4 * q;                                            // + c*16 rows, + nt*16
+    const float* b1p = W.l1b + 4 * q;
+    float4 w1n[4], w2n[4], b1n;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { w1n[c] = w1p[c]; w2n[c] = *reinterpret_cast<const float4*>(w2p + (int64_t)c * 16 * FF); }
+    b1n = *reinterpret_cast<const float4*>(b1p);
+    for (int nt = 0; nt < FF / 16; ++nt) {
+        float4 w1c[4], w2c[4];
+        const float4 b1c = b1n;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w1c[c] = w1n[c]; w2c[c] = w2n[c]; }
+        if (nt + 1 < FF / 16) {                                     // prefetch the next hidden tile's fragments
+            const float4* np1 = w1p + (int64_t)(nt + 1) * 16 * (E / 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                w1n[c] = np1[c];
+                w2n[c] = *reinterpret_cast<const float4*>(w2p + (int64_t)c * 16 * FF + (nt + 1) * 16);
+            }
+            b1n = *reinterpret_cast<const float4*>(b1p + (nt + 1) * 16);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            f32x4 u = {b1c.x, b1c.y, b1c.z, b1c.w};                 // bias of hidden unit 4q + r
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                u = mfma16(w1c[c].x, hf[tt][4 * c + 0], u); u = mfma16(w1c[c].y, hf[tt][4 * c + 1], u);
+                u = mfma16(w1c[c].z, hf[tt][4 * c + 2], u); u = mfma16(w1c[c].w, hf[tt][4 * c + 3], u);
+            }
+            const float u0 = fmaxf(u[0], 0.0f), u1 = fmaxf(u[1], 0.0f), u2 = fmaxf(u[2], 0.0f), u3 = fmaxf(u[3], 0.0f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[tt][c] = mfma16(u0, w2c[c].x, acc[tt][c]); acc[tt][c] = mfma16(u1, w2c[c].y, acc[tt][c]);
+                acc[tt][c] = mfma16(u2, w2c[c].z, acc[tt][c]); acc[tt][c] = mfma16(u3, w2c[c].w, acc[tt][c]);
+            }
+        }
+    }
+    // ---- + b2 + residual, LayerNorm2 -------------------------------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        float x[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float bias = W.l2b[16 * c + jl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[c][r] = (acc[tt][c][r] + bias) + hin[(tok0 + 16 * tt + 4 * q + r) * E + 16 * c + jl];
+        }
+        ln_rows(x, W.n2w, W.n2b, jl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t tok = tok0 + 16 * tt + 4 * q + r;
+            if (tok < a.T) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hout[tok * E + 16 * c + jl] = x[c][r];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------- mean over time + LayerNorm
+__global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.Bp) return;
+    float v = 0.0f;
+    if (b < a.B) {
+        float s = 0.0f;
+        for (int t = 0; t < a.S; ++t) s += a.h0[(b * a.S + t) * E + lane];
+        const float m = s / (float)a.S;
+        const float mean = wave_sum(m) * (1.0f / E);
+        const float d = m - mean;
+        const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.0f / E) + LN_EPS);
+        v = d * rstd * a.lnw[lane] + a.lnb[lane];
+        if (a.sv_mean) a.sv_mean[b * E + lane] = m;
+    }
+    a.feats[b * FEAT + a.out_col + lane] = v;
+}
+
+int64_t tf_padded_tokens(int64_t B, int S) { return round_up(B * S, TOK_PER_WG); }
+
+int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
+    if (a.B == 0) return 0;
+    MCTSQ_CHECK(a.S >= 1 && a.S <= 32, "transformer encoder: seq_len %d outside 1..32", a.S);
+    MCTSQ_CHECK(a.Tp % TOK_PER_WG == 0 && a.Tp >= a.T && a.T == a.B * a.S, "transformer encoder: bad token padding");
+    MCTSQ_CHECK(a.NS >= 1 && a.NS * a.S <= AROWS, "transformer encoder: samples per workgroup");
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp * E / 256)), dim3(256), 0, st, a);
+    const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / TOK_PER_WG);
+    for (int l = 0; l < 2; ++l) {
+        hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(256), 0, st, a, l);
+        hipLaunchKernelGGL(tf_ffn_kernel, dim3(ffn_grid), dim3(256), 0, st, a, l);
+    }
+    hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mctsq

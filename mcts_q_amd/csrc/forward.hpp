@@ -30,8 +30,10 @@ void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, co
                     int64_t Bp, float* feats, const SlotSave* sv);
 bool fill_mlp_args(MlpArgs& ma, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
                    int64_t Bp, float* feats, const SlotSave* sv);
+// floats of forward scratch: feature rows [Bp][192] + token buffers of the transformer slots
+int64_t forward_ws_floats(const NetLayout& L, int64_t Bp);
 int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
-                 float* feats, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
+                 float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
                  void* ev_encoders_done);
 
 }  // namespace mctsq

@@ -68,6 +68,24 @@ struct MlpArgs {
 };
 int launch_mlp_fwd(const MlpArgs& a, bool save, hipStream_t st);
 
+// ---------------- Transformer encoder (dqn_per.py:80-101) ----------------
+struct TfLayerW {
+    const float *inw, *inb, *ow, *ob, *l1w, *l1b, *l2w, *l2b, *n1w, *n1b, *n2w, *n2b;
+};
+struct TfArgs {
+    const float* x;                      // [B][S][Fd]
+    const float *pos, *ew, *eb;          // positional table [500][64], embedding Linear(F,64)
+    TfLayerW layer[2];
+    const float *lnw, *lnb;
+    int S, Fd, F, tf, out_col, NS;       // NS = whole samples per attention workgroup (NS*S <= 128)
+    int64_t B, Bp, T, Tp;                // T = B*S tokens, Tp = T padded to 256
+    float *h0, *h1;                      // [Tp][64] ping-pong token activations
+    float* feats;                        // [Bp][192]
+    float* sv_mean;                      // training: [Bp][64] mean over time before the final LayerNorm
+};
+int64_t tf_padded_tokens(int64_t B, int S);
+int launch_tf_fwd(const TfArgs& a, hipStream_t st);
+
 // ---------------- head ----------------
 struct HeadArgs {
     const float* feats;                  // [Bp][192]

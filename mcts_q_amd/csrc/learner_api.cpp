@@ -51,8 +51,8 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
     const int64_t Bp = round_up(B > 0 ? B : 1, TILE);
     P->Bp = Bp;
     Carver c;
-    P->feats_t = c.take(Bp * FEAT); P->q_t = c.take(Bp * L.A); P->qnext = c.take(Bp);
-    P->feats_p = c.take(Bp * FEAT); P->q_p = c.take(Bp * L.A);
+    P->feats_t = c.take(forward_ws_floats(L, Bp)); P->q_t = c.take(Bp * L.A); P->qnext = c.take(Bp);
+    P->feats_p = c.take(forward_ws_floats(L, Bp)); P->q_p = c.take(Bp * L.A);
     P->dq = c.take(Bp * DQ_LD); P->dfeat = c.take(Bp * FEAT);
     for (int i = 0; i + 1 < L.n_fc; ++i) {
         P->act[i] = c.take(Bp * L.fc_out[i]);

@@ -84,6 +84,30 @@ def test_forward_matches_oracle_batched(combo, B):
     np.testing.assert_allclose(out["vmax"].cpu().numpy(), q.max(1), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("B", [1, 6, 43, 300])
+@pytest.mark.parametrize("name", ["transformer_transformer_gru_per_relu", "transformer_gru_mlp_per_relu",
+                                  "transformer_transformer_gru_std_relu"])
+def test_transformer_forward_matches_oracle_batched(name, B):
+    """Transformer encoders at ragged batch sizes (attention workgroups hold 5 / 12 whole samples)."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, f"qnet_{name}.npz"))
+    g = torch.Generator().manual_seed(B)
+    price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
+        torch.rand(B, 3, 2, generator=g)
+    ref64 = qnet_numpy.q_forward(sd, cfg, price.numpy(), process.numpy(), gas.numpy(), np.float64)
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    out = net(price.cuda(), process.cuda(), gas.cuda())
+    q = out["q"].cpu().numpy()
+    scale = np.abs(ref64).max()
+    err = np.abs(q - ref64).max() / scale
+    print(f"{name} B={B}: HIP vs fp64 {err:.2e}")
+    assert err <= 1e-5
+    srt = np.sort(ref64, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2e-5 * scale
+    assert np.array_equal(out["argmax"].cpu().numpy()[clear], ref64.argmax(1)[clear])
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     import mcts_q_amd._lib as L
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmctsq_hip.so")
