@@ -18,14 +18,14 @@ from .qnet import DeviceQNet
 
 class DeviceLearner:
     def __init__(self, spec: NetSpec, device="cuda:0", gamma=0.99, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 max_grad_norm=10.0, process_group=None):
+                 max_grad_norm=10.0, process_group=None, policy: DeviceQNet | None = None):
         if not torch.cuda.is_available():
             raise MctsqError("DeviceLearner needs a GPU: the HIP path has no CPU fallback")
         self.spec, self.device = spec, torch.device(device)
         self.desc = spec.c_desc()
         n = spec.n_flat
         z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.policy = DeviceQNet(spec, self.device)
+        self.policy = policy if policy is not None else DeviceQNet(spec, self.device)
         self.target = DeviceQNet(spec, self.device)
         self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
         self.gamma, self.lr, self.betas, self.eps = float(gamma), float(lr), betas, float(eps)

@@ -122,6 +122,17 @@ class DevicePER:
                                        ptr(idx), ptr(prio), idx.numel(), self.alpha, self._st()))
         self._max_dirty = True
 
+    def set_priorities_exact(self, prio):
+        """Install priorities for all live entries in logical order (checkpoint import).  The
+        reference's priorities are 1.0 or fp32 |td| values, i.e. exactly representable in fp32."""
+        prio = np.asarray(prio, dtype=np.float64)
+        if len(prio) != self.size:
+            raise ValueError("priority list length differs from the number of stored transitions")
+        p32 = prio.astype(np.float32)
+        if not np.array_equal(p32.astype(np.float64), prio):
+            raise MctsqError("checkpoint priorities are not fp32-representable (not written by PER-DQN)")
+        self.update_priorities(np.arange(self.size), p32)
+
     # ---- export (checkpoint interchange, dqn_per.py:487-492) ----------------------------
     def logical_priorities(self):
         p = self.prio.cpu().numpy()

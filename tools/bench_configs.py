@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Times the BASELINE.json configurations that are not bench.py's headline line (run on the GPU box):
+leaf evaluation for each encoder mix at its configured batch, with HIP-event kernel time and the
+fp32-MFMA roofline fraction.  Prints one JSON object per line."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from mcts_q_amd import NetSpec
+from mcts_q_amd.qnet import DeviceQNet
+from mcts_q_amd.hipevents import HipEvent
+from bench import forward_flops, seeded_net
+
+CASES = [("gru/gru/gru", 4096), ("conv/conv/mlp", 4096), ("conv/gru/mlp", 4096),
+         ("transformer/transformer/gru", 16384), ("transformer/transformer/gru", 4096), ("gru/gru/gru", 512),
+         ("gru/gru/gru", 16384), ("gru/gru/gru", 65536)]
+for combo, B in CASES:
+    pe, pr, ga = combo.split("/")
+    cfg = dict(price=pe, process=pr, gas=ga, act="relu", flavor="per")
+    spec = NetSpec.from_cfg(cfg)
+    _, sd = seeded_net(cfg)
+    net = DeviceQNet(spec).load_state_dict(sd)
+    x = [torch.rand(B, 25, 1).cuda(), torch.rand(B, 10, 6).cuda(), torch.rand(B, 3, 2).cuda()]
+    out = net(*x)
+    for _ in range(5):
+        net(*x, out=out)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    n = 30
+    e0, e1 = HipEvent(), HipEvent()
+    e0.record(st)
+    for _ in range(n):
+        net(*x, out=out)
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_ms(e1) / n
+    enc, head = forward_flops(spec)
+    tf = (enc + head) * B / (ms * 1e-3) / 1e12
+    print(json.dumps({"encoders": combo, "batch": B, "ms_per_forward": ms, "leaf_evals_per_s": B / (ms * 1e-3),
+                      "flops_per_leaf": enc + head, "achieved_TFLOPs": tf, "frac_fp32_mfma_peak": tf / 157.3}), flush=True)
