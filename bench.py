@@ -130,21 +130,30 @@ def main():
     ap.add_argument("--replay", type=int, default=1_000_000, help="replay entries per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="collective backend (nccl = RCCL; gloo only to rehearse "
+                                                     "several ranks on one GPU)")
     args = ap.parse_args()
+    if os.environ.get("MCTSQ_BENCH_DEBUG"):          # dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MCTSQ_BENCH_DEBUG"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
-    from mcts_q_amd import NetSpec
+    from mcts_q_amd import NetSpec, parallel
     from mcts_q_amd.qnet import DeviceQNet
     from mcts_q_amd.hipevents import HipEvent
 
@@ -168,7 +177,7 @@ def main():
     def max_over_ranks(x):
         if world > 1:
             t = torch.tensor([x], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            parallel.all_reduce(t, dist.ReduceOp.MAX, dist.group.WORLD)
             return float(t.item())
         return x
 
@@ -212,10 +221,11 @@ def main():
     if not args.no_train:
         from mcts_q_amd.learner import DeviceLearner
         from mcts_q_amd.per import DevicePER
-        Bt = max(1, args.train_batch // world)
+        Bg = args.train_batch                     # GLOBAL batch: the shards are sampled as one buffer
         N = args.replay
-        L = DeviceLearner(spec, dev, process_group=dist.group.WORLD if world > 1 else None).load_state_dict(sd)
-        buf = DevicePER(N, device=dev)
+        group = dist.group.WORLD if world > 1 else None
+        L = DeviceLearner(spec, dev, process_group=group).load_state_dict(sd)
+        buf = DevicePER(N, device=dev, mass_capacity=N * world)
         gen = torch.Generator(device=dev).manual_seed(100 + rank)
         chunk = 250_000
         for s0 in range(0, N, chunk):
@@ -229,16 +239,17 @@ def main():
         buf.update_priorities(torch.arange(N, device=dev), torch.from_numpy(pr).to(dev))
         tsteps = max(10, min(args.steps, 100))
         twarm = max(3, min(args.warmup, 10))
-        u_all = torch.from_numpy(np.random.RandomState(3654 + rank).random_sample((tsteps + twarm, Bt))).to(dev)
+        # the SAME uniforms on every rank (shared seed): each rank serves the draws in its mass interval
+        u_all = torch.from_numpy(np.random.RandomState(3654).random_sample((tsteps + twarm, Bg))).to(dev)
 
         def train_step(i):
-            idx, phys, w = buf.sample_indices(u_all[i])
-            if world > 1:                        # IS weights are normalised by the GLOBAL max (dqn_per.py:299)
-                wmax_inv = buf.last_local_wmax.clone()
-                dist.all_reduce(wmax_inv, op=dist.ReduceOp.MAX)
-                w = w * (buf.last_local_wmax / wmax_inv).float()
+            if world == 1:
+                idx, phys, w = buf.sample_indices(u_all[i])
+            else:
+                smp = parallel.sharded_sample(buf, u_all[i], group)
+                idx, phys, w = smp["idx"], smp["phys"], smp["w"]
             batch = buf.gather(phys)
-            abs_td = L.compute_grad(batch, w)
+            abs_td = L.compute_grad(batch, w, global_batch=Bg)
             L.apply_grad(tau=0.005)
             buf.update_priorities(idx, abs_td)
 
@@ -251,11 +262,12 @@ def main():
         barrier()
         twall = max_over_ranks(time.perf_counter() - t0)
         train = {"metric": "PER-DQN train steps/sec (gru/gru/gru, 1M-entry sum-tree replay per rank, "
-                           f"global batch {Bt * world})", "value": tsteps / twall, "unit": "train steps/s",
+                           f"global batch {Bg})", "value": tsteps / twall, "unit": "train steps/s",
                  "steps": tsteps, "warmup": twarm, "ms_per_step": twall / tsteps * 1e3,
-                 "global_batch": Bt * world, "batch_per_gpu": Bt, "replay_entries_per_gpu": N,
-                 "scaling": "strong (global batch fixed, split over ranks; one flat-gradient all-reduce)",
-                 "transitions_per_s": tsteps * Bt * world / twall, "loss_last": float(L.loss.item())}
+                 "global_batch": Bg, "replay_entries_per_gpu": N,
+                 "scaling": "strong (global batch fixed; replay shards sampled as one buffer, each rank "
+                            "back-propagates its own draws; one flat-gradient all-reduce)",
+                 "transitions_per_s": tsteps * Bg / twall, "loss_last": float(L.loss.item())}
 
     if rank == 0:
         res = {

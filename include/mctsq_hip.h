@@ -127,29 +127,51 @@ int mctsq_polyak(const float* d_params, float* d_target, int64_t n, double tau, 
  * logical index 0; size = live entries. */
 int64_t mctsq_per_tree_words(int64_t capacity);
 int mctsq_per_mass_shift(int64_t capacity);
-/* push K entries (dqn_per.py:265-267): they take physical slots (head+size+i) % capacity, get
- * priority *d_maxprio (device scalar fp64 holding max over live priorities, default 1.0), and
- * their state rows are copied from d_rows_* ([K,row] fp32, staged by the caller).  The caller
- * advances head/size on the host: size' = min(size+K, cap), head' = (head + max(0,size+K-cap)) % cap. */
+/* mass_capacity (push / sample / update): the capacity the fixed-point scale is derived from -
+ * pass `capacity` for a single buffer, the SUM of all shard capacities when several shards are
+ * sampled as one buffer (sharded entry points below), so the concatenated mass cannot overflow. */
+/* push K entries (dqn_per.py:265-267): they take physical slots (head+size+i) % capacity and get
+ * priority *d_maxprio (device scalar fp64 holding max over live priorities, default 1.0); the caller
+ * copies the state rows itself and advances head/size on the host:
+ * size' = min(size+K, cap), head' = (head + max(0,size+K-cap)) % cap. */
 int mctsq_per_push(uint64_t* d_tree, double* d_prio, const double* d_maxprio, int64_t capacity,
-                   int64_t head, int64_t size, int64_t K, double alpha, void* stream);
+                   int64_t head, int64_t size, int64_t K, double alpha, int64_t mass_capacity,
+                   void* stream);
 /* recompute *d_maxprio = max(prio[live]) (1.0 if empty): the O(N) max() of dqn_per.py:265. */
 int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, int64_t size,
                           double* d_maxprio, void* d_ws, int64_t ws_bytes, void* stream);
 /* sample (dqn_per.py:283-301): d_u fp64 [B] uniforms in [0,1) -> d_idx int64 [B] LOGICAL
  * indices, d_phys int64 [B] physical slots, d_w fp32 [B] IS weights (N p_i)^-beta / max.
- * d_wmax (optional, fp64 [1]) receives that max before normalisation, so data-parallel ranks can
- * renormalise by the global maximum. */
+ * d_wmax (optional, fp64 [1]) receives that max before normalisation. */
 int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
                      int64_t size, const double* d_u, int64_t B, double alpha, double beta,
-                     int64_t* d_idx, int64_t* d_phys, float* d_w, double* d_wmax, void* d_ws,
-                     int64_t ws_bytes, void* stream);
+                     int64_t mass_capacity, int64_t* d_idx, int64_t* d_phys, float* d_w,
+                     double* d_wmax, void* d_ws, int64_t ws_bytes, void* stream);
 /* update_priorities (dqn_per.py:307-314): prio[idx[i]] = p[i] sequentially (last duplicate
  * wins); d_idx LOGICAL int64 [B], d_newprio fp32 [B].  d_stamp: int32 [capacity] scratch owned by
  * the buffer, all -1 on entry (the call leaves it all -1 again). */
 int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t capacity,
                      int64_t head, int64_t size, const int64_t* d_idx, const float* d_newprio,
-                     int64_t B, double alpha, void* stream);
+                     int64_t B, double alpha, int64_t mass_capacity, void* stream);
+
+/* ---- sharded replay (no reference counterpart: SURVEY.md section 8e).  W ranks each own one ring;
+ * together they are sampled as ONE buffer whose logical order is the concatenation of the shards
+ * in rank order, with the same exact-integer inverse CDF:
+ *   1. every rank: mctsq_per_total_mass -> its root mass; all-gather the W masses (and sizes);
+ *   2. every rank: mctsq_per_shard_targets on the SAME B uniforms -> which draws fall into its
+ *      interval of the concatenated mass line (d_mine) and their local integer targets;
+ *   3. compact its own draws, mctsq_per_sample_at with n_total / mass_total of the whole buffer
+ *      -> local indices, raw fp64 IS weights and their local max;
+ *   4. all-reduce(MAX) the max, mctsq_per_normalize_weights -> fp32 weights. */
+int mctsq_per_total_mass(const uint64_t* d_tree, int64_t capacity, uint64_t* d_mass, void* stream);
+int mctsq_per_shard_targets(const double* d_u, int64_t B, const uint64_t* d_shard_mass, int world,
+                            int rank, uint64_t* d_targets, int32_t* d_mine, void* stream);
+int mctsq_per_sample_at(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
+                        int64_t size, const uint64_t* d_targets, int64_t B, double alpha, double beta,
+                        int64_t mass_capacity, double n_total, double mass_total, int64_t* d_idx,
+                        int64_t* d_phys, double* d_w64, double* d_wmax, void* stream);
+int mctsq_per_normalize_weights(const double* d_w64, int64_t B, const double* d_wmax, float* d_w,
+                                void* stream);
 /* gather the sampled transitions (dqn_per.py:293, 415-452): rows are 96-float padded
  * [price 25 | process 10x6 | gas 3x2 | pad] records; outputs are the six window tensors the
  * learner consumes plus actions / rewards / dones. */

@@ -43,11 +43,16 @@ SIGNATURES = {
     "mctsq_per_tree_words": (_i64, [_i64]),
     "mctsq_per_mass_shift": (_i32, [_i64]),
     "mctsq_per_workspace_bytes": (_i64, [_i64, _i64]),
-    "mctsq_per_push": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _vp]),
+    "mctsq_per_push": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f64, _i64, _vp]),
     "mctsq_per_refresh_max": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
-    "mctsq_per_sample": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _vp, _vp, _vp, _vp, _vp,
+    "mctsq_per_sample": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _i64, _vp, _vp, _vp, _vp, _vp,
                                 _i64, _vp]),
-    "mctsq_per_update": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _f64, _vp]),
+    "mctsq_per_update": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _f64, _i64, _vp]),
+    "mctsq_per_total_mass": (_i32, [_vp, _i64, _vp, _vp]),
+    "mctsq_per_shard_targets": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "mctsq_per_sample_at": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _i64, _f64, _f64, _vp, _vp,
+                                   _vp, _vp, _vp]),
+    "mctsq_per_normalize_weights": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "mctsq_per_gather": (_i32, [_vp] * 6 + [_i64] + [_vp] * 10),
 }
 

@@ -223,14 +223,20 @@ static int check_ring(int64_t capacity, int64_t head, int64_t size) {
     return 0;
 }
 
+static int check_mass_cap(int64_t capacity, int64_t mass_capacity) {
+    MCTSQ_CHECK(mass_capacity >= capacity && mass_capacity <= (int64_t)1 << 36,
+                "mass_capacity %lld must be >= capacity and <= 2^36", (long long)mass_capacity);
+    return 0;
+}
+
 int mctsq_per_push(uint64_t* d_tree, double* d_prio, const double* d_maxprio, int64_t capacity, int64_t head,
-                   int64_t size, int64_t K, double alpha, void* stream) {
-    if (check_ring(capacity, head, size)) return -1;
+                   int64_t size, int64_t K, double alpha, int64_t mass_capacity, void* stream) {
+    if (check_ring(capacity, head, size) || check_mass_cap(capacity, mass_capacity)) return -1;
     MCTSQ_CHECK(d_tree && d_prio && d_maxprio, "NULL device pointer");
     MCTSQ_CHECK(K >= 0 && K <= capacity, "push count %lld outside [0, capacity]", (long long)K);
     if (K == 0) return 0;
     return launch_per_push((unsigned long long*)d_tree, d_prio, d_maxprio, capacity, head, size, K, alpha,
-                           (hipStream_t)stream);
+                           mass_capacity, (hipStream_t)stream);
 }
 
 int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, int64_t size, double* d_maxprio,
@@ -242,28 +248,65 @@ int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, 
 }
 
 int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
-                     const double* d_u, int64_t B, double alpha, double beta, int64_t* d_idx, int64_t* d_phys,
-                     float* d_w, double* d_wmax, void* d_ws, int64_t ws_bytes, void* stream) {
-    if (check_ring(capacity, head, size)) return -1;
+                     const double* d_u, int64_t B, double alpha, double beta, int64_t mass_capacity,
+                     int64_t* d_idx, int64_t* d_phys, float* d_w, double* d_wmax, void* d_ws, int64_t ws_bytes,
+                     void* stream) {
+    if (check_ring(capacity, head, size) || check_mass_cap(capacity, mass_capacity)) return -1;
     MCTSQ_CHECK(size >= 1, "cannot sample from an empty buffer");
     MCTSQ_CHECK(B >= 0, "negative batch");
     if (B == 0) return 0;
     MCTSQ_CHECK(d_tree && d_prio && d_u && d_idx && d_phys && d_w, "NULL device pointer");
     MCTSQ_CHECK(d_ws && ws_bytes >= B * 8, "workspace too small");
     return launch_per_sample((const unsigned long long*)d_tree, d_prio, capacity, head, size, d_u, B, alpha,
-                             beta, d_idx, d_phys, d_w, d_wmax, (double*)d_ws, (hipStream_t)stream);
+                             beta, mass_capacity, d_idx, d_phys, d_w, d_wmax, (double*)d_ws, (hipStream_t)stream);
+}
+
+int mctsq_per_total_mass(const uint64_t* d_tree, int64_t capacity, uint64_t* d_mass, void* stream) {
+    MCTSQ_CHECK(d_tree && d_mass, "NULL device pointer");
+    return launch_per_total_mass((const unsigned long long*)d_tree, capacity, (unsigned long long*)d_mass,
+                                 (hipStream_t)stream);
+}
+
+int mctsq_per_shard_targets(const double* d_u, int64_t B, const uint64_t* d_shard_mass, int world, int rank,
+                            uint64_t* d_targets, int32_t* d_mine, void* stream) {
+    MCTSQ_CHECK(B >= 0 && world >= 1 && world <= 64 && rank >= 0 && rank < world, "bad shard geometry");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_u && d_shard_mass && d_targets && d_mine, "NULL device pointer");
+    return launch_per_shard_targets(d_u, B, (const unsigned long long*)d_shard_mass, world, rank,
+                                    (unsigned long long*)d_targets, d_mine, (hipStream_t)stream);
+}
+
+int mctsq_per_sample_at(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
+                        const uint64_t* d_targets, int64_t B, double alpha, double beta, int64_t mass_capacity,
+                        double n_total, double mass_total, int64_t* d_idx, int64_t* d_phys, double* d_w64,
+                        double* d_wmax, void* stream) {
+    if (check_ring(capacity, head, size) || check_mass_cap(capacity, mass_capacity)) return -1;
+    MCTSQ_CHECK(size >= 1, "cannot sample from an empty buffer");
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_tree && d_prio && d_targets && d_idx && d_phys && d_w64, "NULL device pointer");
+    return launch_per_sample_at((const unsigned long long*)d_tree, d_prio, capacity, head, size,
+                                (const unsigned long long*)d_targets, B, alpha, beta, mass_capacity, n_total,
+                                mass_total, d_idx, d_phys, d_w64, d_wmax, (hipStream_t)stream);
+}
+
+int mctsq_per_normalize_weights(const double* d_w64, int64_t B, const double* d_wmax, float* d_w, void* stream) {
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_w64 && d_wmax && d_w, "NULL device pointer");
+    return launch_per_normalize(d_w64, B, d_wmax, d_w, (hipStream_t)stream);
 }
 
 int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t capacity, int64_t head,
                      int64_t size, const int64_t* d_idx, const float* d_newprio, int64_t B, double alpha,
-                     void* stream) {
-    if (check_ring(capacity, head, size)) return -1;
+                     int64_t mass_capacity, void* stream) {
+    if (check_ring(capacity, head, size) || check_mass_cap(capacity, mass_capacity)) return -1;
     MCTSQ_CHECK(B >= 0, "negative batch");
     if (B == 0) return 0;
     MCTSQ_CHECK(d_tree && d_prio && d_stamp && d_idx && d_newprio, "NULL device pointer");
     MCTSQ_CHECK(B < ((int64_t)1 << 31), "update batch too large");
     return launch_per_update((unsigned long long*)d_tree, d_prio, d_stamp, capacity, head, d_idx, d_newprio, B, alpha,
-                             (hipStream_t)stream);
+                             mass_capacity, (hipStream_t)stream);
 }
 
 int mctsq_per_gather(const float* d_states, const float* d_next_states, const int32_t* d_actions,

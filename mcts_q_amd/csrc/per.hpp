@@ -26,13 +26,22 @@ struct PerGatherArgs {
     float *rew, *done;
 };
 
-int launch_per_sample(const unsigned long long* tree, const double* prio, int64_t cap, int64_t head,
-                      int64_t size, const double* u, int64_t B, double alpha, double beta, int64_t* idx,
+typedef unsigned long long per_u64;
+int launch_per_sample(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
+                      const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
                       int64_t* phys, float* w, double* wmax, double* ws_w64, hipStream_t st);
-int launch_per_update(unsigned long long* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, const int64_t* idx,
-                      const float* newp, int64_t B, double alpha, hipStream_t st);
-int launch_per_push(unsigned long long* tree, double* prio, const double* maxprio, int64_t cap, int64_t head,
-                    int64_t size, int64_t K, double alpha, hipStream_t st);
+int launch_per_sample_at(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
+                         const per_u64* targets, int64_t B, double alpha, double beta, int64_t mass_cap,
+                         double n_total, double mass_total, int64_t* idx, int64_t* phys, double* w64, double* wmax,
+                         hipStream_t st);
+int launch_per_normalize(const double* w64, int64_t B, const double* wmax, float* w, hipStream_t st);
+int launch_per_shard_targets(const double* u, int64_t B, const per_u64* shard_mass, int world, int rank,
+                             per_u64* targets, int32_t* mine, hipStream_t st);
+int launch_per_total_mass(const per_u64* tree, int64_t cap, per_u64* out, hipStream_t st);
+int launch_per_update(per_u64* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, const int64_t* idx,
+                      const float* newp, int64_t B, double alpha, int64_t mass_cap, hipStream_t st);
+int launch_per_push(per_u64* tree, double* prio, const double* maxprio, int64_t cap, int64_t head,
+                    int64_t size, int64_t K, double alpha, int64_t mass_cap, hipStream_t st);
 int launch_per_refresh_max(const double* prio, int64_t n_live, double* out, double* ws_part, int nparts_cap,
                            hipStream_t st);
 int launch_per_gather(const PerGatherArgs& a, hipStream_t st);

@@ -94,8 +94,10 @@ __device__ u64 prefix_mass(const u64* tree, const PerTree& T, int64_t n, int lan
 __global__ __launch_bounds__(256) void per_sample_kernel(const u64* __restrict__ tree, PerTree T,
                                                          const double* __restrict__ prio, int64_t cap,
                                                          int64_t head, int64_t size,
-                                                         const double* __restrict__ u, int64_t B,
-                                                         double alpha, double beta, int shift,
+                                                         const double* __restrict__ u,
+                                                         const u64* __restrict__ targets, int64_t B,
+                                                         double alpha, double beta, int shift, double n_eff,
+                                                         double mass_eff,
                                                          int64_t* __restrict__ idx_out,
                                                          int64_t* __restrict__ phys_out,
                                                          double* __restrict__ w64) {
@@ -107,9 +109,14 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const u64* __restrict__
     u64 sc = wave_incl_scan(v, lane);
     const u64 M = shfl_u64(sc, 63);
     // u = k / 2^53 exactly (numpy random_sample); target t = floor(k * M / 2^53)
-    const u64 k = (u64)(u[draw] * 9007199254740992.0);
-    const u64 hi = __umul64hi(k, M), lo = k * M;
-    u64 t = (hi << 11) | (lo >> 53);
+    u64 t;
+    if (targets) {
+        t = targets[draw];                                   // sharded: local integer target
+    } else {
+        const u64 k = (u64)(u[draw] * 9007199254740992.0);
+        const u64 hi = __umul64hi(k, M), lo = k * M;
+        t = (hi << 11) | (lo >> 53);
+    }
     if (head != 0) {                                         // logical order starts at `head`
         const u64 H = prefix_mass(tree, T, head, lane);
         const u64 tail = M - H;
@@ -134,9 +141,61 @@ __global__ __launch_bounds__(256) void per_sample_kernel(const u64* __restrict__
         idx_out[draw] = logical;
         phys_out[draw] = g;
         const double p = mctsq_pow_det(prio[g], alpha);
-        const double ratio = ((double)size * p) * ldexp(1.0, shift) / (double)M;
+        const double ratio = ((n_eff > 0.0 ? n_eff : (double)size) * p) * ldexp(1.0, shift) /
+                             (mass_eff > 0.0 ? mass_eff : (double)M);
         w64[draw] = mctsq_pow_det(ratio, -beta);
     }
+}
+
+// global targets of a sharded buffer: shard `rank` owns [prefix, prefix + mass[rank]) of the
+// concatenated mass line; t = floor(k * M / 2^53) exactly as the single-buffer form
+__global__ __launch_bounds__(256) void per_shard_targets_kernel(const double* __restrict__ u, int64_t B,
+                                                                const u64* __restrict__ shard_mass, int world,
+                                                                int rank, u64* __restrict__ targets,
+                                                                int32_t* __restrict__ mine) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    u64 M = 0, prefix = 0;
+    for (int r = 0; r < world; ++r) {
+        if (r < rank) prefix += shard_mass[r];
+        M += shard_mass[r];
+    }
+    const u64 k = (u64)(u[i] * 9007199254740992.0);
+    const u64 hi = __umul64hi(k, M), lo = k * M;
+    const u64 t = (hi << 11) | (lo >> 53);
+    const bool m = t >= prefix && t - prefix < shard_mass[rank];
+    targets[i] = m ? t - prefix : 0;
+    mine[i] = m ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void per_total_mass_kernel(const u64* __restrict__ tree, PerTree T,
+                                                            u64* __restrict__ out) {
+    const int lane = threadIdx.x, top = T.nlev - 1;
+    u64 v = lane < T.cnt[top] ? tree[T.off[top] + lane] : 0;
+    v = wave_incl_scan(v, lane);
+    if (lane == 63) *out = v;
+}
+
+__global__ __launch_bounds__(1024) void per_weight_max_kernel(const double* __restrict__ w64, int64_t B,
+                                                              double* __restrict__ wmax) {
+    __shared__ double red[16];
+    double mx = 0.0;
+    for (int64_t i = threadIdx.x; i < B; i += 1024) mx = fmax(mx, w64[i]);
+    for (int d = 32; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = red[0];
+        for (int i = 1; i < 16; ++i) mx = fmax(mx, red[i]);
+        *wmax = mx;
+    }
+}
+
+__global__ __launch_bounds__(256) void per_weight_scale_kernel(const double* __restrict__ w64, int64_t B,
+                                                               const double* __restrict__ wmax,
+                                                               float* __restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < B) w[i] = (float)(w64[i] / *wmax);
 }
 
 __global__ __launch_bounds__(1024) void per_weight_norm_kernel(const double* __restrict__ w64, int64_t B,
@@ -289,37 +348,73 @@ int per_mass_shift(int64_t cap) {
 }
 
 int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
-                      const double* u, int64_t B, double alpha, double beta, int64_t* idx, int64_t* phys,
-                      float* w, double* wmax, double* ws_w64, hipStream_t st) {
+                      const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
+                      int64_t* phys, float* w, double* wmax, double* ws_w64, hipStream_t st) {
     PerTree T;
     if (per_tree_desc(cap, &T)) return -1;
-    const int shift = per_mass_shift(cap);
+    const int shift = per_mass_shift(mass_cap);
     hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, tree, T, prio, cap,
-                       head, size, u, B, alpha, beta, shift, idx, phys, ws_w64);
+                       head, size, u, (const u64*)nullptr, B, alpha, beta, shift, 0.0, 0.0, idx, phys, ws_w64);
     hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, ws_w64, B, w, wmax);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
 
+int launch_per_sample_at(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
+                         const u64* targets, int64_t B, double alpha, double beta, int64_t mass_cap, double n_total,
+                         double mass_total, int64_t* idx, int64_t* phys, double* w64, double* wmax,
+                         hipStream_t st) {
+    PerTree T;
+    if (per_tree_desc(cap, &T)) return -1;
+    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, tree, T, prio, cap,
+                       head, size, (const double*)nullptr, targets, B, alpha, beta, per_mass_shift(mass_cap),
+                       n_total, mass_total, idx, phys, w64);
+    if (wmax) hipLaunchKernelGGL(per_weight_max_kernel, dim3(1), dim3(1024), 0, st, w64, B, wmax);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_per_normalize(const double* w64, int64_t B, const double* wmax, float* w, hipStream_t st) {
+    hipLaunchKernelGGL(per_weight_scale_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, w64, B, wmax, w);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_per_shard_targets(const double* u, int64_t B, const u64* shard_mass, int world, int rank, u64* targets,
+                             int32_t* mine, hipStream_t st) {
+    hipLaunchKernelGGL(per_shard_targets_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, u, B,
+                       shard_mass, world, rank, targets, mine);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_per_total_mass(const u64* tree, int64_t cap, u64* out, hipStream_t st) {
+    PerTree T;
+    if (per_tree_desc(cap, &T)) return -1;
+    hipLaunchKernelGGL(per_total_mass_kernel, dim3(1), dim3(64), 0, st, tree, T, out);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_per_update(u64* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, const int64_t* idx,
-                      const float* newp, int64_t B, double alpha, hipStream_t st) {
+                      const float* newp, int64_t B, double alpha, int64_t mass_cap, hipStream_t st) {
     PerTree T;
     if (per_tree_desc(cap, &T)) return -1;
     const dim3 grid((unsigned)((B + 255) / 256));
     hipLaunchKernelGGL(per_update_mark_kernel, grid, dim3(256), 0, st, stamp, cap, head, idx, B);
     hipLaunchKernelGGL(per_update_kernel, grid, dim3(256), 0, st, tree, T, prio, stamp, cap, head, idx, newp, B,
-                       alpha, per_mass_shift(cap));
+                       alpha, per_mass_shift(mass_cap));
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_per_push(u64* tree, double* prio, const double* maxprio, int64_t cap, int64_t head, int64_t size,
-                    int64_t K, double alpha, hipStream_t st) {
+                    int64_t K, double alpha, int64_t mass_cap, hipStream_t st) {
     PerTree T;
     if (per_tree_desc(cap, &T)) return -1;
     const int64_t first = (head + size) % cap;
     hipLaunchKernelGGL(per_push_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, tree, T, prio, cap,
-                       first, K, maxprio, alpha, per_mass_shift(cap));
+                       first, K, maxprio, alpha, per_mass_shift(mass_cap));
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -13,6 +13,7 @@ import torch
 
 from ._lib import lib, ptr, MctsqError
 from .netdesc import NetSpec
+from .parallel import all_reduce
 from .qnet import DeviceQNet
 
 
@@ -47,10 +48,20 @@ class DeviceLearner:
         return self
 
     # ---- gradient of the IS-weighted TD loss (dqn_per.py:455-470) ------------------------------
-    def compute_grad(self, batch: dict, isw: torch.Tensor):
+    def compute_grad(self, batch: dict, isw: torch.Tensor, global_batch: int | None = None):
         """batch: dict from DevicePER.gather (sprice.. ngas, act, rew, done) on this device; isw fp32 [B].
-        Fills self.grad (unclipped) and self.loss; returns |td| fp32 [B] (the new priorities)."""
+        Fills self.grad (unclipped; after the all-reduce when data-parallel) and self.loss (local mean);
+        returns |td| fp32 [B] (the new priorities).  `global_batch` = draws over all ranks (default
+        B * world); B may be 0 on a rank that received no draw."""
         B = int(isw.numel())
+        if global_batch is None:
+            global_batch = B * self.world
+        if B == 0:
+            self.grad.zero_(); self.loss.zero_()
+            if self.world > 1:
+                all_reduce(self.grad, group=self.group)
+                all_reduce(self.loss, group=self.group)
+            return torch.empty(0, dtype=torch.float32, device=self.device)
         need = lib.check(lib.mctsq_dqn_grad_workspace_bytes(C.byref(self.desc), B))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -60,10 +71,12 @@ class DeviceLearner:
             ptr(batch["sprice"]), ptr(batch["sprocess"]), ptr(batch["sgas"]),
             ptr(batch["nprice"]), ptr(batch["nprocess"]), ptr(batch["ngas"]),
             ptr(batch["act"]), ptr(batch["rew"]), ptr(batch["done"]), ptr(isw),
-            self.gamma, 1.0 / self.world, B, ptr(self.grad), ptr(self.loss), ptr(abs_td), None, None,
+            self.gamma, B / float(global_batch), B, ptr(self.grad), ptr(self.loss), ptr(abs_td), None, None,
             ptr(self._ws), self._ws.numel(), self._st()))
         if self.world > 1:                      # data-parallel: one flat-gradient all-reduce (RCCL)
-            torch.distributed.all_reduce(self.grad, group=self.group)
+            all_reduce(self.grad, group=self.group)
+            self.loss.mul_(B / float(global_batch))           # global mean = sum_r (B_r / B) * local mean
+            all_reduce(self.loss, group=self.group)
         return abs_td
 
     # ---- clip_grad_norm_(10) + Adam.step (+ Polyak) (dqn_per.py:471-472, 510-516) ---------------

@@ -17,10 +17,13 @@ ROW = 96          # floats per stored state record (91 used): price 25 | process
 
 
 class DevicePER:
-    def __init__(self, capacity: int, alpha: float = 0.6, device="cuda:0"):
+    def __init__(self, capacity: int, alpha: float = 0.6, device="cuda:0", mass_capacity: int | None = None):
         if not torch.cuda.is_available():
             raise MctsqError("DevicePER needs a GPU: the HIP path has no CPU fallback")
         self.capacity, self.alpha = int(capacity), float(alpha)
+        # capacity the fixed-point mass scale is derived from: the sum over all shards when this
+        # ring is one shard of a data-parallel buffer (mctsq_hip.h, "sharded replay")
+        self.mass_capacity = int(mass_capacity) if mass_capacity is not None else self.capacity
         self.device = torch.device(device)
         d = self.device
         self.head, self.size = 0, 0
@@ -75,7 +78,7 @@ class DevicePER:
         self.rewards[slots] = torch.as_tensor(rewards, device=d).to(torch.float32)
         self.dones[slots] = torch.as_tensor(dones, device=d).to(torch.float32)
         lib.check(lib.mctsq_per_push(ptr(self.tree), ptr(self.prio), ptr(self.maxprio), self.capacity,
-                                     self.head, self.size, K, self.alpha, self._st()))
+                                     self.head, self.size, K, self.alpha, self.mass_capacity, self._st()))
         over = max(0, self.size + K - self.capacity)
         self.size = min(self.size + K, self.capacity)
         self.head = (self.head + over) % self.capacity
@@ -93,9 +96,49 @@ class DevicePER:
         w = torch.empty(B, dtype=torch.float32, device=self.device)
         ws = self._ws_for(B)
         lib.check(lib.mctsq_per_sample(ptr(self.tree), ptr(self.prio), self.capacity, self.head, self.size,
-                                       ptr(u), B, self.alpha, beta, ptr(idx), ptr(phys), ptr(w),
+                                       ptr(u), B, self.alpha, beta, self.mass_capacity, ptr(idx), ptr(phys), ptr(w),
                                        ptr(self.last_local_wmax), ptr(ws), ws.numel(), self._st()))
         return idx, phys, w
+
+    # ---- shard primitives (one ring = one shard of a buffer sampled as a whole; parallel.py) ------
+    def total_mass(self):
+        """Root of the sum-tree as an int64 device tensor [1] (uint64 bit pattern, < 2^62)."""
+        out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        lib.check(lib.mctsq_per_total_mass(ptr(self.tree), self.capacity, ptr(out), self._st()))
+        return out
+
+    def shard_targets(self, u, shard_mass, rank: int):
+        """u fp64 [B] (the SAME draws on every rank), shard_mass int64 [W] -> (local integer targets
+        int64 [B], mine int32 [B])."""
+        u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
+        shard_mass = shard_mass.to(self.device, torch.int64).contiguous()
+        B = u.numel()
+        targets = torch.empty(B, dtype=torch.int64, device=self.device)
+        mine = torch.empty(B, dtype=torch.int32, device=self.device)
+        lib.check(lib.mctsq_per_shard_targets(ptr(u), B, ptr(shard_mass), shard_mass.numel(), int(rank),
+                                              ptr(targets), ptr(mine), self._st()))
+        return targets, mine
+
+    def sample_at(self, targets, n_total: float, mass_total: float, beta: float = 0.4):
+        """Local draws at explicit integer targets -> (logical idx, physical slot, raw fp64 weights,
+        their max as fp64 [1])."""
+        targets = targets.to(self.device, torch.int64).contiguous()
+        B = targets.numel()
+        idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        phys = torch.empty(B, dtype=torch.int64, device=self.device)
+        w64 = torch.empty(B, dtype=torch.float64, device=self.device)
+        wmax = torch.zeros(1, dtype=torch.float64, device=self.device)
+        if B:
+            lib.check(lib.mctsq_per_sample_at(ptr(self.tree), ptr(self.prio), self.capacity, self.head, self.size,
+                                              ptr(targets), B, self.alpha, beta, self.mass_capacity, float(n_total),
+                                              float(mass_total), ptr(idx), ptr(phys), ptr(w64), ptr(wmax),
+                                              self._st()))
+        return idx, phys, w64, wmax
+
+    def normalize_weights(self, w64, wmax):
+        w = torch.empty(w64.numel(), dtype=torch.float32, device=self.device)
+        lib.check(lib.mctsq_per_normalize_weights(ptr(w64), w64.numel(), ptr(wmax), ptr(w), self._st()))
+        return w
 
     def gather(self, phys):
         """Batch assembly (dqn_per.py:415-452) on the device: six window tensors + a, r, done."""
@@ -119,7 +162,7 @@ class DevicePER:
         if idx.numel() != prio.numel():
             raise ValueError("indices / priorities length mismatch")
         lib.check(lib.mctsq_per_update(ptr(self.tree), ptr(self.prio), ptr(self.stamp), self.capacity, self.head, self.size,
-                                       ptr(idx), ptr(prio), idx.numel(), self.alpha, self._st()))
+                                       ptr(idx), ptr(prio), idx.numel(), self.alpha, self.mass_capacity, self._st()))
         self._max_dirty = True
 
     def set_priorities_exact(self, prio):

@@ -116,3 +116,44 @@ def test_large_buffer_statistics_and_roundtrip():
     buf.update_priorities(np.array([123456, 123456]), np.array([0.0, 2.0], dtype=np.float32))
     idx2, _, w2 = buf.sample_indices(u)
     assert (idx2.cpu().numpy() == 123456).all() and (w2.cpu().numpy() == 1.0).all()
+
+
+def test_sharded_sampling_kernels_match_single_buffer_oracle():
+    """Two rings on one GPU sampled as ONE buffer (concatenation in shard order) through the shard
+    entry points: indices, ownership and IS weights equal the single-buffer oracle's bit for bit.
+    (The collective plumbing around these calls is covered on CPU by tests/test_parallel_cpu.py.)"""
+    from mcts_q_amd.per import DevicePER
+    cap, B, world = 3000, 256, 2
+    rng = np.random.RandomState(9)
+    sizes = [cap, 1700]
+    prios = [np.abs(rng.standard_normal(n)).astype(np.float32) for n in sizes]
+    prios[0][::13] = 0.0
+    shards = []
+    for n, pr in zip(sizes, prios):
+        s = DevicePER(cap, mass_capacity=world * cap)
+        s.push_rows(_rows(n), np.zeros(n), np.zeros(n), _rows(n), np.zeros(n))
+        s.update_priorities(np.arange(n), pr)
+        shards.append(s)
+    u = rng.random_sample(B)
+    masses = torch.cat([s.total_mass() for s in shards])
+    n_total, mass_total = float(sum(sizes)), float(sum(int(m) for m in masses.tolist()))
+    concat = np.concatenate(prios).astype(np.float64)
+    idx_or, w_or, _ = per_numpy.fixed_point_sample(concat, u, capacity=world * cap)
+    m_or, _ = per_numpy.masses(concat, 0.6, per_numpy.mass_shift(world * cap))
+    assert int(masses[0]) == int(m_or[:sizes[0]].sum()) and int(masses[1]) == int(m_or[sizes[0]:].sum())
+    parts, gmax = [], torch.zeros(1, dtype=torch.float64, device="cuda")
+    for r, s in enumerate(shards):
+        targets, mine = s.shard_targets(u, masses, r)
+        draw = torch.nonzero(mine).squeeze(1)
+        idx, phys, w64, wmax = s.sample_at(targets[draw], n_total, mass_total)
+        gmax = torch.maximum(gmax, wmax)
+        parts.append((s, draw, idx, w64))
+    served = torch.zeros(B, dtype=torch.int32, device="cuda")
+    for r, (s, draw, idx, w64) in enumerate(parts):
+        w = s.normalize_weights(w64, gmax)
+        lo = sum(sizes[:r])
+        d = draw.cpu().numpy()
+        served[draw] += 1
+        assert np.array_equal(idx.cpu().numpy() + lo, idx_or[d])
+        assert np.array_equal(w.cpu().numpy(), w_or[d])
+    assert (served == 1).all()
