@@ -75,8 +75,8 @@ int64_t forward_ws_floats(const NetLayout& L, int64_t Bp) {
     return n;
 }
 
-static void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
-                         int64_t Bp, float* feats, float* hbuf) {
+void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
+                  int64_t Bp, float* feats, float* hbuf, const SlotSave* sv) {
     memset(&t, 0, sizeof(t));
     t.x = x;
     t.pos = params + e.tfm.pos; t.ew = params + e.tfm.ew; t.eb = params + e.tfm.eb;
@@ -89,8 +89,15 @@ static void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const 
     }
     t.lnw = params + e.tfm.lnw; t.lnb = params + e.tfm.lnb;
     t.S = e.S; t.Fd = e.Fd; t.F = e.F; t.tf = e.tf; t.out_col = slot * E; t.NS = 128 / e.S;
-    t.B = B; t.Bp = Bp; t.T = B * e.S; t.Tp = tf_padded_tokens(Bp, e.S);
-    t.h0 = hbuf; t.h1 = hbuf + t.Tp * E; t.feats = feats;
+    t.B = B; t.Bvalid = B; t.Bp = Bp; t.T = B * e.S; t.Tp = tf_padded_tokens(Bp, e.S);
+    float *h0 = hbuf, *h1 = hbuf + t.Tp * E;                  // inference: ping-pong
+    for (int l = 0; l < 2; ++l) { t.buf[l].hin = h0; t.buf[l].hmid = h1; t.buf[l].hout = h0; }
+    t.feats = feats;
+    if (sv) {                       // training: every stage keeps its output; padded samples are processed too
+        t.buf[0] = sv->t_buf[0]; t.buf[1] = sv->t_buf[1];
+        t.sv_mean = sv->t_mean; t.sv_xe = sv->t_xe;
+        t.B = Bp; t.T = Bp * e.S;
+    }
 }
 
 // TripleEncoderDQN.forward (dqn_per.py:232-236) + leaf epilogue.  `sv` != NULL keeps the
@@ -106,7 +113,7 @@ int forward_impl(const NetLayout& L, const float* params, const float* const x[3
     MlpArgs ma;
     const bool has_mlp = fill_mlp_args(ma, L, params, x, B, Bp, feats, sv);
     const bool has_tf = L.enc[0].kind == MCTSQ_ENC_TRANSFORMER || L.enc[1].kind == MCTSQ_ENC_TRANSFORMER;
-    MCTSQ_CHECK(!(has_tf && sv), "training path: the transformer encoder is not built into this library yet");
+    (void)has_tf;
     HeadArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
@@ -130,7 +137,7 @@ int forward_impl(const NetLayout& L, const float* params, const float* const x[3
         for (int s = 0; s < 2; ++s) {
             if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
             TfArgs t;
-            fill_tf_args(t, L.enc[s], params, x[s], s, B, Bp, feats, hbuf);
+            fill_tf_args(t, L.enc[s], params, x[s], s, B, Bp, feats, hbuf, sv ? &sv[s] : nullptr);
             if (launch_tf_fwd(t, st)) return -1;
             hbuf += 2 * t.Tp * E;
         }

@@ -24,22 +24,29 @@ __global__ __launch_bounds__(256) void tf_embed_kernel(TfArgs a) {
     const int c = (int)(gid & 63);
     if (tok >= a.Tp) return;
     float v = 0.0f;
-    if (tok < a.T) {
+    if (tok < a.Bvalid * a.S) {
         const int64_t b = tok / a.S;
         const int t = (int)(tok - b * a.S);
         v = a.eb[c];
         for (int f = 0; f < a.F; ++f) {
             const float x = f < a.Fd ? a.x[tok * a.Fd + f] : time_feature(a.tf, t, f - a.Fd);
             v = fmaf(x, a.ew[c * a.F + f], v);
+            if (a.sv_xe && c == 0) a.sv_xe[tok * 8 + f] = x;
         }
+        if (a.sv_xe && c >= a.F && c < 8) a.sv_xe[tok * 8 + c] = 0.0f;
         v += a.pos[t * E + c];
+    } else if (a.sv_xe && c < 8) {
+        a.sv_xe[tok * 8 + c] = 0.0f;
     }
-    a.h0[tok * E + c] = v;
+    a.buf[0].hin[tok * E + c] = v;
 }
 
 // LayerNorm over the 64 columns of rows held in the MFMA D layout: x[c][r] is column 16c + jl of
 // row 4q + r; the reduction runs over c (registers) and the 16 lanes of the row group.
-__device__ __forceinline__ void ln_rows(float x[4][4], const float* lnw, const float* lnb, int jl) {
+// Training: sv_x ([rows][64], row stride 64, pointing at the tile's first row, NULL to skip) keeps
+// the pre-norm sum and sv_st ([rows][2]) its (mean, rstd); rows >= nrows are not written.
+__device__ __forceinline__ void ln_rows(float x[4][4], const float* lnw, const float* lnb, int jl, int q,
+                                        float* sv_x = nullptr, float* sv_st = nullptr, int nrows = 16) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float mean = row16_sum((x[0][r] + x[1][r]) + (x[2][r] + x[3][r])) * (1.0f / E);
@@ -47,6 +54,11 @@ __device__ __forceinline__ void ln_rows(float x[4][4], const float* lnw, const f
 #pragma unroll
         for (int c = 0; c < 4; ++c) { d[c] = x[c][r] - mean; ss += d[c] * d[c]; }
         const float rstd = 1.0f / sqrtf(row16_sum(ss) * (1.0f / E) + LN_EPS);
+        if (sv_x && 4 * q + r < nrows) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sv_x[(4 * q + r) * E + 16 * c + jl] = x[c][r];
+            if (jl == 0) { sv_st[(4 * q + r) * 2] = mean; sv_st[(4 * q + r) * 2 + 1] = rstd; }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) x[c][r] = d[c] * rstd * lnw[16 * c + jl] + lnb[16 * c + jl];
     }
@@ -61,8 +73,9 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
     __shared__ __attribute__((aligned(16))) float hs[AROWS * AHLD];
     __shared__ __attribute__((aligned(16))) float qkv[AROWS * QLD];
     const TfLayerW& W = a.layer[layer];
-    const float* hin = a.h0;                              // ping-pong: h0 -> (attn) h1 -> (ffn) h0
-    float* hout = a.h1;
+    const TfLayerBuf& Bf = a.buf[layer];
+    const float* hin = Bf.hin;
+    float* hout = Bf.hmid;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
     const int S = a.S, NS = a.NS;
     const int64_t sample0 = (int64_t)blockIdx.x * NS;
@@ -98,8 +111,14 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
             const float sc = nt < 4 ? 0.25f : 1.0f;                  // q / sqrt(head_dim)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                qkv[(32 * w + 4 * q + r) * QLD + 16 * nt + jl] = (acc0[r] + bias) * sc;
-                qkv[(32 * w + 16 + 4 * q + r) * QLD + 16 * nt + jl] = (acc1[r] + bias) * sc;
+                const float v0 = (acc0[r] + bias) * sc, v1 = (acc1[r] + bias) * sc;
+                const int r0 = 32 * w + 4 * q + r, r1 = r0 + 16;
+                qkv[r0 * QLD + 16 * nt + jl] = v0;
+                qkv[r1 * QLD + 16 * nt + jl] = v1;
+                if (Bf.qkv) {
+                    if (r0 < rows) Bf.qkv[(tok0 + r0) * G3 + 16 * nt + jl] = v0;
+                    if (r1 < rows) Bf.qkv[(tok0 + r1) * G3 + 16 * nt + jl] = v1;
+                }
             }
         }
     }
@@ -168,7 +187,10 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
         const float4* p = reinterpret_cast<const float4*>(&qkv[(rbase + jl) * QLD + 16 * q]);
         float af[16];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float4 v = p[c]; af[4 * c] = v.x; af[4 * c + 1] = v.y; af[4 * c + 2] = v.z; af[4 * c + 3] = v.w; }
+        for (int c = 0; c < 4; ++c) {
+            const float4 v = p[c]; af[4 * c] = v.x; af[4 * c + 1] = v.y; af[4 * c + 2] = v.z; af[4 * c + 3] = v.w;
+            if (Bf.ctx && rbase + jl < rows) reinterpret_cast<float4*>(Bf.ctx + (tok0 + rbase + jl) * E + 16 * q)[c] = v;
+        }
         float x[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -184,7 +206,8 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[c][r] = (acc[r] + bias) + hs[(rbase + 4 * q + r) * AHLD + 16 * c + jl];
         }
-        ln_rows(x, W.n1w, W.n1b, jl);
+        ln_rows(x, W.n1w, W.n1b, jl, q, Bf.x1 ? Bf.x1 + (tok0 + rbase) * E : nullptr,
+                Bf.x1 ? Bf.st1 + (tok0 + rbase) * 2 : nullptr, rows - rbase);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rbase + 4 * q + r;
@@ -200,8 +223,9 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
 // hout = LayerNorm2(hin + W2 relu(W1 hin + b1) + b2).  One wave = 64 tokens (4 tiles of 16).
 __global__ __launch_bounds__(256) void tf_ffn_kernel(TfArgs a, int layer) {
     const TfLayerW& W = a.layer[layer];
-    const float* hin = a.h1;
-    float* hout = a.h0;
+    const TfLayerBuf& Bf = a.buf[layer];
+    const float* hin = Bf.hmid;
+    float* hout = Bf.hout;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jl = lane & 15, q = lane >> 4;
     const int64_t tok0 = ((int64_t)blockIdx.x * 4 + w) * TOK_PER_WAVE;
     if (tok0 >= a.T) return;
@@ -267,7 +291,12 @@ __global__ __launch_bounds__(256) void tf_ffn_kernel(TfArgs a, int layer) {
             for (int r = 0; r < 4; ++r)
                 x[c][r] = (acc[tt][c][r] + bias) + hin[(tok0 + 16 * tt + 4 * q + r) * E + 16 * c + jl];
         }
-        ln_rows(x, W.n2w, W.n2b, jl);
+        {
+            const int64_t t0 = tok0 + 16 * tt;
+            const int64_t left = a.T - t0;
+            ln_rows(x, W.n2w, W.n2b, jl, q, Bf.x2 ? Bf.x2 + t0 * E : nullptr, Bf.x2 ? Bf.st2 + t0 * 2 : nullptr,
+                    (int)(left < 16 ? (left < 0 ? 0 : left) : 16));
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t tok = tok0 + 16 * tt + 4 * q + r;
@@ -287,7 +316,7 @@ __global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) {
     float v = 0.0f;
     if (b < a.B) {
         float s = 0.0f;
-        for (int t = 0; t < a.S; ++t) s += a.h0[(b * a.S + t) * E + lane];
+        for (int t = 0; t < a.S; ++t) s += a.buf[1].hout[(b * a.S + t) * E + lane];
         const float m = s / (float)a.S;
         const float mean = wave_sum(m) * (1.0f / E);
         const float d = m - mean;

@@ -15,6 +15,9 @@ struct SlotSave {
     float *c_h1, *c_h2, *c_d2, *c_d1;
     // gas/EUA MLP (kernels.hpp: MlpArgs)
     float *m_x, *m_m0, *m_d1, *m_d0;
+    // Transformer (kernels.hpp: TfArgs): per-stage token buffers and records
+    TfLayerBuf t_buf[2];
+    float *t_mean, *t_xe;
 };
 
 struct HeadOut {
@@ -32,6 +35,8 @@ bool fill_mlp_args(MlpArgs& ma, const NetLayout& L, const float* params, const f
                    int64_t Bp, float* feats, const SlotSave* sv);
 // floats of forward scratch: feature rows [Bp][192] + token buffers of the transformer slots
 int64_t forward_ws_floats(const NetLayout& L, int64_t Bp);
+void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
+                  int64_t Bp, float* feats, float* hbuf, const SlotSave* sv);
 int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
                  float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
                  void* ev_encoders_done);

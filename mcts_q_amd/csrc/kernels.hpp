@@ -72,16 +72,28 @@ int launch_mlp_fwd(const MlpArgs& a, bool save, hipStream_t st);
 struct TfLayerW {
     const float *inw, *inb, *ow, *ob, *l1w, *l1b, *l2w, *l2b, *n1w, *n1b, *n2w, *n2b;
 };
+struct TfLayerBuf {
+    float *hin, *hmid, *hout;
+    // training record (NULL for inference)
+    float* qkv;                          // [Tp][192] in_proj output (q already scaled by 1/4)
+    float* ctx;                          // [Tp][64] attention output before out_proj
+    float *x1, *st1;                     // [Tp][64] pre-LayerNorm1 sum, [Tp][2] (mean, rstd)
+    float *x2, *st2;                     // same for LayerNorm2
+};
 struct TfArgs {
     const float* x;                      // [B][S][Fd]
     const float *pos, *ew, *eb;          // positional table [500][64], embedding Linear(F,64)
     TfLayerW layer[2];
     const float *lnw, *lnb;
     int S, Fd, F, tf, out_col, NS;       // NS = whole samples per attention workgroup (NS*S <= 128)
-    int64_t B, Bp, T, Tp;                // T = B*S tokens, Tp = T padded to 256
-    float *h0, *h1;                      // [Tp][64] ping-pong token activations
+    int64_t B, Bp, T, Tp;                // samples / tokens the block kernels process (training: B = Bp)
+    int64_t Bvalid;                      // samples present in x (rows beyond are treated as zero windows)
+    // token activations [Tp][64]: layer l reads hin, attention writes hmid, FFN writes hout.
+    // Inference ping-pongs two buffers; training gives every stage its own (kept for backward).
+    TfLayerBuf buf[2];
     float* feats;                        // [Bp][192]
     float* sv_mean;                      // training: [Bp][64] mean over time before the final LayerNorm
+    float* sv_xe;                        // training: [Tp][8] embedded-input rows incl. time features
 };
 int64_t tf_padded_tokens(int64_t B, int S);
 int launch_tf_fwd(const TfArgs& a, hipStream_t st);

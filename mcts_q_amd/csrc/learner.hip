@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, float* __restri
     for (int k = 1; k < jl.njobs; ++k)
         if ((int)blockIdx.x >= jl.job[k].blk0) ji = k;
     const WJob& J = jl.job[ji];
+    if (!J.A) return;                                         // partials written by another kernel
     const int lb = blockIdx.x - J.blk0, per = J.mblocks * J.nblocks;
     const int split = lb / per, rem = lb - split * per, mb = rem / J.nblocks, nb = rem - mb * J.nblocks;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jl_ = lane & 15, q = lane >> 4;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const fl
     float acc = 0.0f;
     for (int sp = 0; sp < J.nsplit; ++sp) acc += p[(int64_t)sp * stride];
     if (le < mn) {
-        if (J.out_w >= 0 && J.Bm) {
+        if (J.out_w >= 0) {
             const int64_t m = le / J.N, n = le - m * J.N;
             grad[J.out_w + m * J.out_ldm + n * J.out_sn] = acc;
         }

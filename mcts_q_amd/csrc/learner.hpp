@@ -53,6 +53,22 @@ struct ConvBwdArgs {
 int launch_conv_bwd(const ConvBwdArgs& a, hipStream_t st);
 int launch_mlp_bwd(const MlpArgs& a, hipStream_t st);
 
+// ---- Transformer encoder backward (enc_tf_bwd.hip) ----
+struct TfBwdArgs {
+    TfArgs f;                   // forward arguments incl. the training record
+    const float* dfeat;         // [Bp][192]
+    int nsb, ntb;               // whole samples per attention-backward workgroup; FFN token blocks
+    float *w1t[2], *w2t[2];     // W1^T [64][2048], W2^T [2048][64] per layer
+    float *dy2[2], *dx2[2], *p2[2], *dy1[2], *dx1[2], *p1[2];   // [Tp][64] per layer
+    float* dqkv[2];             // [Tp][192]
+    float* dhpart;              // [16][Tp][64] FFN input-gradient slabs, one per hidden group
+    float *wpart1[2], *wpart2[2];   // FFN weight-gradient partials per token block
+    float* pfin;                // [Bp][64] dfeat * xhat of the final LayerNorm
+    float* dh0;                 // [Tp][64] gradient of the embedding output
+};
+int launch_tf_bwd(const TfBwdArgs& a, hipStream_t st);
+int tf_bwd_token_blocks(int64_t Tp);
+
 // ---- weight gradients: dW[m][n] = sum_k A[k][m] * Bm[k][n], bias[m] = sum_k A[k][m] ----
 // Split over K into `nsplit` chunks whose partial results are reduced in a fixed order, so the
 // gradient is bitwise reproducible (no float atomics).

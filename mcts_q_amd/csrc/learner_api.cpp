@@ -25,6 +25,12 @@ struct SlotPlan {                      // float offsets; which fields are used d
     int64_t h, r, z, n, hn, g;          // gru
     int64_t c_h1, c_h2, c_d2, c_d1;     // conv
     int64_t m_x, m_m0, m_d1, m_d0;      // mlp
+    // transformer: [l] per layer
+    int64_t t_e0, t_hmid[2], t_hout[2], t_qkv[2], t_ctx[2], t_x1[2], t_st1[2], t_x2[2], t_st2[2], t_mean, t_xe;
+    int64_t t_w1t[2], t_w2t[2], t_dy2[2], t_dx2[2], t_p2[2], t_dy1[2], t_dx1[2], t_p1[2], t_dqkv[2];
+    int64_t t_dhpart, t_wp1[2], t_wp2[2], t_pfin, t_dh0;
+    int64_t Tp, T;
+    int ntb;
 };
 
 struct TrainPlan {
@@ -79,8 +85,26 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
         } else if (e.kind == MCTSQ_ENC_MLP) {
             g.m_x = c.take(Bp * 16); g.m_m0 = c.take(Bp * E); g.m_d1 = c.take(Bp * E); g.m_d0 = c.take(Bp * E);
             pf += job_partial_floats(E, 3 * e.F, Bp) + job_partial_floats(E, E, Bp);
+        } else if (e.kind == MCTSQ_ENC_TRANSFORMER) {
+            const int64_t Tp = tf_padded_tokens(Bp, e.S), T = Bp * S;
+            g.Tp = Tp; g.T = T; g.ntb = tf_bwd_token_blocks(Tp);
+            g.t_e0 = c.take(Tp * E); g.t_mean = c.take(Bp * E); g.t_xe = c.take(Tp * 8);
+            g.t_pfin = c.take(Bp * E); g.t_dh0 = c.take(Tp * E); g.t_dhpart = c.take(16 * Tp * E);
+            for (int l = 0; l < 2; ++l) {
+                g.t_hmid[l] = c.take(Tp * E); g.t_hout[l] = c.take(Tp * E); g.t_qkv[l] = c.take(Tp * G3);
+                g.t_ctx[l] = c.take(Tp * E); g.t_x1[l] = c.take(Tp * E); g.t_st1[l] = c.take(Tp * 2);
+                g.t_x2[l] = c.take(Tp * E); g.t_st2[l] = c.take(Tp * 2);
+                g.t_w1t[l] = c.take(2048 * E); g.t_w2t[l] = c.take(2048 * E);
+                g.t_dy2[l] = c.take(Tp * E); g.t_dx2[l] = c.take(Tp * E); g.t_p2[l] = c.take(Tp * E);
+                g.t_dy1[l] = c.take(Tp * E); g.t_dx1[l] = c.take(Tp * E); g.t_p1[l] = c.take(Tp * E);
+                g.t_dqkv[l] = c.take(Tp * G3);
+                g.t_wp1[l] = c.take((int64_t)g.ntb * (2048 * E + 2048));
+                g.t_wp2[l] = c.take((int64_t)g.ntb * (E * 2048 + E));
+                pf += job_partial_floats(G3, E, T) + job_partial_floats(E, E, T) + 5 * job_partial_floats(E, 0, T);
+            }
+            pf += job_partial_floats(E, e.F, T) + job_partial_floats((int)(S * E), 0, Bp) + 2 * job_partial_floats(E, 0, Bp);
         } else {
-            MCTSQ_CHECK(false, "training path: encoder kind %d is not built into this library yet", e.kind);
+            MCTSQ_CHECK(false, "training path: unknown encoder kind %d", e.kind);
         }
     }
     for (int i = 0; i < L.n_fc; ++i) pf += job_partial_floats(L.fc_out[i], L.fc_in[i], Bp);
@@ -115,6 +139,21 @@ struct JobBuilder {
         j.blk0 = jl.nblocks_total;
         jl.nblocks_total += j.nsplit * j.mblocks * j.nblocks;
         MCTSQ_CHECK(K % 4 == 0, "weight-gradient contraction length must be a multiple of 4");
+        return 0;
+    }
+    // partial sums [nsplit][M*N + M] already written by another kernel at float offset `part_off`
+    // relative to the partial base; only the ordered reduction runs for this job
+    int add_external(int64_t part_off, int M, int N, int nsplit, int64_t out_w, int64_t out_ldm, int64_t out_sn,
+                     int64_t out_b) {
+        if (nlists == 0 || lists[nlists - 1].njobs == MAX_WJOBS) {
+            MCTSQ_CHECK(nlists < 4, "too many weight-gradient jobs");
+            ++nlists;
+        }
+        WJobList& jl = lists[nlists - 1];
+        WJob& j = jl.job[jl.njobs++];
+        j.A = nullptr; j.Bm = nullptr; j.M = M; j.N = N; j.K = 0; j.kchunk = 4; j.nsplit = nsplit;
+        j.part_off = part_off; j.out_w = out_w; j.out_ldm = out_ldm; j.out_sn = out_sn; j.out_b = out_b;
+        j.mblocks = 0; j.nblocks = 1; j.blk0 = jl.nblocks_total;
         return 0;
     }
 };
@@ -169,6 +208,20 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         v.h = ws + g.h; v.r = ws + g.r; v.z = ws + g.z; v.n = ws + g.n; v.hn = ws + g.hn; v.g = ws + g.g;
         v.c_h1 = ws + g.c_h1; v.c_h2 = ws + g.c_h2; v.c_d2 = ws + g.c_d2; v.c_d1 = ws + g.c_d1;
         v.m_x = ws + g.m_x; v.m_m0 = ws + g.m_m0; v.m_d1 = ws + g.m_d1; v.m_d0 = ws + g.m_d0;
+        if (L.enc[s].kind == MCTSQ_ENC_TRANSFORMER) {
+            for (int l = 0; l < 2; ++l) {
+                TfLayerBuf& b = v.t_buf[l];
+                b.hin = l == 0 ? ws + g.t_e0 : ws + g.t_hout[0];
+                b.hmid = ws + g.t_hmid[l]; b.hout = ws + g.t_hout[l]; b.qkv = ws + g.t_qkv[l]; b.ctx = ws + g.t_ctx[l];
+                b.x1 = ws + g.t_x1[l]; b.st1 = ws + g.t_st1[l]; b.x2 = ws + g.t_x2[l]; b.st2 = ws + g.t_st2[l];
+                // rows [T, Tp) of the FFN backward's token-major inputs are read but never produced
+                if (g.Tp > g.T) {
+                    MCTSQ_HIP(hipMemsetAsync(b.hmid + g.T * E, 0, (size_t)(g.Tp - g.T) * E * sizeof(float), st));
+                    MCTSQ_HIP(hipMemsetAsync(ws + g.t_dx2[l] + g.T * E, 0, (size_t)(g.Tp - g.T) * E * sizeof(float), st));
+                }
+            }
+            v.t_mean = ws + g.t_mean; v.t_xe = ws + g.t_xe;
+        }
     }
     float* sv_act[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i + 1 < L.n_fc; ++i) sv_act[i] = ws + P.act[i];
@@ -216,6 +269,22 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
             ma.dfeat = ws + P.dfeat;
             if (launch_mlp_bwd(ma, st)) return -1;
         }
+        for (int s = 0; s < 2; ++s) {
+            if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
+            const SlotPlan& g = P.slot[s];
+            TfBwdArgs tb;
+            memset(&tb, 0, sizeof(tb));
+            fill_tf_args(tb.f, L.enc[s], d_params, xs[s], s, B, Bp, ws + P.feats_p, nullptr, &sv[s]);
+            tb.dfeat = ws + P.dfeat; tb.nsb = 64 / L.enc[s].S; tb.ntb = g.ntb;
+            for (int l = 0; l < 2; ++l) {
+                tb.w1t[l] = ws + g.t_w1t[l]; tb.w2t[l] = ws + g.t_w2t[l];
+                tb.dy2[l] = ws + g.t_dy2[l]; tb.dx2[l] = ws + g.t_dx2[l]; tb.p2[l] = ws + g.t_p2[l];
+                tb.dy1[l] = ws + g.t_dy1[l]; tb.dx1[l] = ws + g.t_dx1[l]; tb.p1[l] = ws + g.t_p1[l];
+                tb.dqkv[l] = ws + g.t_dqkv[l]; tb.wpart1[l] = ws + g.t_wp1[l]; tb.wpart2[l] = ws + g.t_wp2[l];
+            }
+            tb.dhpart = ws + g.t_dhpart; tb.pfin = ws + g.t_pfin; tb.dh0 = ws + g.t_dh0;
+            if (launch_tf_bwd(tb, st)) return -1;
+        }
     }
     // 6. weight gradients: every tensor is one (or a few) K-contractions
     JobBuilder jb;
@@ -250,6 +319,27 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
             if (jb.add(ws + g.dsc, 1, 0, ws + g.c_h2, E, 0, 1, E, K, e.conv.aw, E, 1, e.conv.ab)) return -1;
             if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnw)) return -1;
             if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnb)) return -1;
+        } else if (e.kind == MCTSQ_ENC_TRANSFORMER) {
+            const int64_t T = g.T;
+            const TfOff& o = e.tfm;
+            for (int l = 0; l < 2; ++l) {
+                const TfLayerOff& t = o.layer[l];
+                const float* hin = l == 0 ? ws + g.t_e0 : ws + g.t_hout[0];
+                if (jb.add(ws + g.t_dqkv[l], G3, 0, hin, E, 0, G3, E, T, t.inw, E, 1, t.inb)) return -1;
+                if (jb.add(ws + g.t_dx1[l], E, 0, ws + g.t_ctx[l], E, 0, E, E, T, t.ow, E, 1, t.ob)) return -1;
+                if (jb.add_external(g.t_wp1[l] - P.partials, 2048, E, g.ntb, t.l1w, E, 1, t.l1b)) return -1;
+                if (jb.add_external(g.t_wp2[l] - P.partials, E, 2048, g.ntb, t.l2w, 2048, 1, -1)) return -1;
+                if (jb.add(ws + g.t_dx2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.l2b)) return -1;
+                if (jb.add(ws + g.t_p1[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n1w)) return -1;
+                if (jb.add(ws + g.t_dy1[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n1b)) return -1;
+                if (jb.add(ws + g.t_p2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n2w)) return -1;
+                if (jb.add(ws + g.t_dy2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n2b)) return -1;
+            }
+            // embedding Linear(F,64) and the positional table rows 0..S-1 (sum over samples)
+            if (jb.add(ws + g.t_dh0, E, 0, ws + g.t_xe, 8, 0, E, e.F, T, o.ew, e.F, 1, o.eb)) return -1;
+            if (jb.add(ws + g.t_dh0, (int64_t)e.S * E, 0, nullptr, 0, 0, e.S * E, 0, Bp, -1, 0, 0, o.pos)) return -1;
+            if (jb.add(ws + g.t_pfin, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, o.lnw)) return -1;
+            if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, o.lnb)) return -1;
         } else {    // mlp
             if (jb.add(ws + g.m_d0, E, 0, ws + g.m_x, 16, 0, E, 3 * e.F, Bp, e.mlp.w0, 3 * e.F, 1, e.mlp.b0)) return -1;
             if (jb.add(ws + g.m_d1, E, 0, ws + g.m_m0, E, 0, E, E, Bp, e.mlp.w1, E, 1, e.mlp.b1)) return -1;
