@@ -202,19 +202,32 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     }
 
     // ---- BPTT ----------------------------------------------------------------------------
+    // The saved activations of step t-1 are fetched while step t's MFMA chain runs, so the
+    // recurrence never waits on HBM/L2 latency.
+    struct StepIn { float rg, zg, ng, hn, hprev, sc; };
+    StepIn cur[4], nxt[4];
+    auto fetch = [&](StepIn (&d)[4], int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = (int64_t)t * Bp + row0 + 4 * q + r;
+            const int64_t o = row * E + j;
+            d[r].rg = s.sv_r[o]; d[r].zg = s.sv_z[o]; d[r].ng = s.sv_n[o]; d[r].hn = s.sv_hn[o];
+            d[r].hprev = s.sv_h[o];                            // block t = h_{t-1}
+            d[r].sc = s.sv_score[row];
+        }
+    };
+    fetch(cur, S - 1);
     float dhc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int t = S - 1; t >= 0; --t) {
         const int buf = t & 1;
+        if (t > 0) fetch(nxt, t - 1);
         float zs[4], dhs[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
             const int64_t row = (int64_t)t * Bp + row0 + i;
-            const int64_t o = row * E + j;
-            const float rg = s.sv_r[o], zg = s.sv_z[o], ng = s.sv_n[o], hn = s.sv_hn[o];
-            const float hprev = s.sv_h[o];                      // block t = h_{t-1}
-            const float sc = s.sv_score[row];
-            const float at = fast_exp2(sc - mrun[r]) * linv[r];
+            const float rg = cur[r].rg, zg = cur[r].zg, ng = cur[r].ng, hn = cur[r].hn, hprev = cur[r].hprev;
+            const float at = fast_exp2(cur[r].sc - mrun[r]) * linv[r];
             const float4 pe = L.pe[t][i];
             const float dsc = at * (((pe.x + pe.y) + (pe.z + pe.w)) - Dd[r]);
             if (wq == 0 && jl == 0) s.bw_dsc[row] = dsc;
@@ -242,7 +255,10 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             acc0 = mfma16(a0.w, wf[4 * c + 3], acc0); acc1 = mfma16(a1.w, wf[16 + 4 * c + 3], acc1); acc2 = mfma16(a2.w, wf[32 + 4 * c + 3], acc2);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dhc[r] = dhs[r] * zs[r] + ((acc0[r] + acc1[r]) + acc2[r]);
+        for (int r = 0; r < 4; ++r) {
+            dhc[r] = dhs[r] * zs[r] + ((acc0[r] + acc1[r]) + acc2[r]);
+            cur[r] = nxt[r];
+        }
     }
 }
 
@@ -259,12 +275,13 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
 // Block = 4 waves = a 64 x 64 output tile of one (job, K split); wave w owns rows 16w..16w+15.
 // A operand lane (m = l&15, k = l>>4) reads A[k0+k][m]; B operand lane (n = l&15, k = l>>4) reads
 // Bm[k0+k][n]: both are 4 rows x 64 contiguous bytes per wave instruction.
-__global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, const float* __restrict__ ws,
+                                                    float* __restrict__ partials) {
     int ji = 0;
     for (int k = 1; k < jl.njobs; ++k)
         if ((int)blockIdx.x >= jl.job[k].blk0) ji = k;
     const WJob& J = jl.job[ji];
-    if (!J.A) return;                                         // partials written by another kernel
+    if (J.a_off < 0) return;                                  // partials written by another kernel
     const int lb = blockIdx.x - J.blk0, per = J.mblocks * J.nblocks;
     const int split = lb / per, rem = lb - split * per, mb = rem / J.nblocks, nb = rem - mb * J.nblocks;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jl_ = lane & 15, q = lane >> 4;
@@ -275,16 +292,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, float* __restri
     const int64_t k1 = k0 + J.kchunk < J.K ? k0 + J.kchunk : J.K;
     const bool m_ok = m0 + jl_ < M;
     const bool do_bias = nb == 0;
-    const int ntile = J.Bm ? min(4, (N - n0 + 15) >> 4) : 0;
-    const float* ap = J.A + (k0 + q) * J.lda + J.a_col0 + m0 + jl_;
-    const float* bp = J.Bm ? J.Bm + (k0 + q) * J.ldb + J.b_col0 + n0 + jl_ : nullptr;
+    const bool has_b = J.b_off >= 0;
+    const int ntile = has_b ? min(4, (N - n0 + 15) >> 4) : 0;
+    const float* ap = ws + J.a_off + (k0 + q) * J.lda + m0 + jl_;
+    const float* bp = has_b ? ws + J.b_off + (k0 + q) * J.ldb + n0 + jl_ : nullptr;
     bool n_ok[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) n_ok[t] = t < ntile && n0 + 16 * t + jl_ < N;
     f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     f32x4 accb = {0, 0, 0, 0};
-    const int64_t astep = 4 * J.lda, bstep = J.Bm ? 4 * J.ldb : 0;
-#pragma unroll 4
+    const int64_t astep = 4 * (int64_t)J.lda, bstep = has_b ? 4 * (int64_t)J.ldb : 0;
+#pragma unroll 8
     for (int64_t k = k0; k < k1; k += 4) {
         const float av = m_ok ? *ap : 0.0f;
         ap += astep;
@@ -335,16 +353,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const fl
     if (le < mn) {
         if (J.out_w >= 0) {
             const int64_t m = le / J.N, n = le - m * J.N;
-            grad[J.out_w + m * J.out_ldm + n * J.out_sn] = acc;
+            grad[J.out_w + m * (int64_t)J.out_ldm + n * (int64_t)J.out_sn] = acc;
         }
     } else if (J.out_b >= 0) {
         grad[J.out_b + (le - mn)] = acc;
     }
 }
 
-int launch_wgrad(const WJobList& jl, float* partials, hipStream_t st) {
-    if (jl.njobs == 0) return 0;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)jl.nblocks_total), dim3(256), 0, st, jl, partials);
+int launch_wgrad(const WJobList& jl, const float* ws, float* partials, hipStream_t st) {
+    if (jl.njobs == 0 || jl.nblocks_total == 0) return 0;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)jl.nblocks_total), dim3(256), 0, st, jl, ws, partials);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -6,7 +6,7 @@
 namespace mctsq {
 
 constexpr int DQ_LD = 16;       // dQ rows are padded to 16 action columns (zeros beyond A)
-constexpr int MAX_WJOBS = 16;   // jobs per wgrad launch (kernel-argument budget)
+constexpr int MAX_WJOBS = 40;   // jobs per wgrad launch (kernel-argument budget: 40 x 80 B)
 
 // ---- TD loss (dqn_per.py:455-467, 474) ----
 struct TdArgs {
@@ -72,20 +72,20 @@ int tf_bwd_token_blocks(int64_t Tp);
 // ---- weight gradients: dW[m][n] = sum_k A[k][m] * Bm[k][n], bias[m] = sum_k A[k][m] ----
 // Split over K into `nsplit` chunks whose partial results are reduced in a fixed order, so the
 // gradient is bitwise reproducible (no float atomics).
-struct WJob {
-    const float* A;             // [K][lda], columns a_col0 .. a_col0+M-1
-    const float* Bm;            // [K][ldb], columns b_col0 .. b_col0+N-1 (NULL: bias only)
-    int64_t lda, ldb, K, kchunk;
+struct WJob {                   // 80 bytes: a whole network's job list fits one kernel-argument block
+    int64_t a_off;              // A = ws + a_off: [K][lda], M columns (column offset folded in); < 0: the
+                                // partials of this job are written by another kernel (reduce only)
+    int64_t b_off;              // Bm = ws + b_off: [K][ldb], N columns; < 0: bias (column sums) only
     int64_t part_off;           // float offset of this job's partials: [nsplit][M*N + M]
-    int64_t out_w, out_ldm, out_sn;   // grad index = out_w + m*out_ldm + n*out_sn (out_w < 0: none)
-    int64_t out_b;              // bias gradient offset (< 0: none)
-    int a_col0, b_col0, M, N, nsplit, mblocks, nblocks, blk0;
+    int32_t out_w, out_b;       // gradient offsets (< 0: none); weight index = out_w + m*out_ldm + n*out_sn
+    int32_t out_ldm, out_sn;
+    int32_t lda, ldb, K, kchunk, M, N, nsplit, mblocks, nblocks, blk0;
 };
 struct WJobList {
     WJob job[MAX_WJOBS];
     int njobs, nblocks_total;
 };
-int launch_wgrad(const WJobList& jl, float* partials, hipStream_t st);
+int launch_wgrad(const WJobList& jl, const float* ws, float* partials, hipStream_t st);
 int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, hipStream_t st);
 
 }  // namespace mctsq

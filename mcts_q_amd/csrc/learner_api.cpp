@@ -118,42 +118,49 @@ struct JobBuilder {
     WJobList lists[4];
     int nlists = 0;
     int64_t part_pos = 0;
-    JobBuilder() { memset(lists, 0, sizeof(lists)); }
-    int add(const float* A, int64_t lda, int a_col0, const float* Bm, int64_t ldb, int b_col0, int M, int N,
-            int64_t K, int64_t out_w, int64_t out_ldm, int64_t out_sn, int64_t out_b) {
+    const float* base;                                   // workspace base every operand lives in
+    explicit JobBuilder(const float* ws) : base(ws) { memset(lists, 0, sizeof(lists)); }
+    WJob* next() {
         if (nlists == 0 || lists[nlists - 1].njobs == MAX_WJOBS) {
-            MCTSQ_CHECK(nlists < 4, "too many weight-gradient jobs");
+            if (nlists >= 4) { set_error("too many weight-gradient jobs"); return nullptr; }
             ++nlists;
         }
         WJobList& jl = lists[nlists - 1];
-        WJob& j = jl.job[jl.njobs++];
-        j.A = A; j.lda = lda; j.a_col0 = a_col0; j.Bm = Bm; j.ldb = ldb; j.b_col0 = b_col0;
-        j.M = M; j.N = Bm ? N : 0; j.K = K;
-        j.kchunk = split_chunk(K);
+        return &jl.job[jl.njobs++];
+    }
+    int add(const float* A, int64_t lda, int a_col0, const float* Bm, int64_t ldb, int b_col0, int M, int N,
+            int64_t K, int64_t out_w, int64_t out_ldm, int64_t out_sn, int64_t out_b) {
+        WJob* jp = next();
+        if (!jp) return -1;
+        WJob& j = *jp;
+        WJobList& jl = lists[nlists - 1];
+        MCTSQ_CHECK(K % 4 == 0 && K < ((int64_t)1 << 31), "weight-gradient contraction length must be a multiple of 4");
+        j.a_off = (A - base) + a_col0; j.lda = (int32_t)lda;
+        j.b_off = Bm ? (Bm - base) + b_col0 : -1; j.ldb = (int32_t)ldb;
+        j.M = M; j.N = Bm ? N : 0; j.K = (int32_t)K;
+        j.kchunk = (int32_t)split_chunk(K);
         j.nsplit = (int)((K + j.kchunk - 1) / j.kchunk);
         j.part_off = part_pos;
         part_pos += (int64_t)j.nsplit * ((int64_t)j.M * j.N + j.M);
-        j.out_w = Bm ? out_w : -1; j.out_ldm = out_ldm; j.out_sn = out_sn; j.out_b = out_b;
+        j.out_w = Bm ? (int32_t)out_w : -1; j.out_ldm = (int32_t)out_ldm; j.out_sn = (int32_t)out_sn;
+        j.out_b = (int32_t)out_b;
         j.mblocks = (M + 63) / 64;
         j.nblocks = j.N > 0 ? (j.N + 63) / 64 : 1;
         j.blk0 = jl.nblocks_total;
         jl.nblocks_total += j.nsplit * j.mblocks * j.nblocks;
-        MCTSQ_CHECK(K % 4 == 0, "weight-gradient contraction length must be a multiple of 4");
         return 0;
     }
     // partial sums [nsplit][M*N + M] already written by another kernel at float offset `part_off`
     // relative to the partial base; only the ordered reduction runs for this job
     int add_external(int64_t part_off, int M, int N, int nsplit, int64_t out_w, int64_t out_ldm, int64_t out_sn,
                      int64_t out_b) {
-        if (nlists == 0 || lists[nlists - 1].njobs == MAX_WJOBS) {
-            MCTSQ_CHECK(nlists < 4, "too many weight-gradient jobs");
-            ++nlists;
-        }
-        WJobList& jl = lists[nlists - 1];
-        WJob& j = jl.job[jl.njobs++];
-        j.A = nullptr; j.Bm = nullptr; j.M = M; j.N = N; j.K = 0; j.kchunk = 4; j.nsplit = nsplit;
-        j.part_off = part_off; j.out_w = out_w; j.out_ldm = out_ldm; j.out_sn = out_sn; j.out_b = out_b;
-        j.mblocks = 0; j.nblocks = 1; j.blk0 = jl.nblocks_total;
+        WJob* jp = next();
+        if (!jp) return -1;
+        WJob& j = *jp;
+        j.a_off = -1; j.b_off = -1; j.M = M; j.N = N; j.K = 0; j.kchunk = 4; j.nsplit = nsplit;
+        j.part_off = part_off; j.out_w = (int32_t)out_w; j.out_ldm = (int32_t)out_ldm; j.out_sn = (int32_t)out_sn;
+        j.out_b = (int32_t)out_b;
+        j.mblocks = 0; j.nblocks = 1; j.blk0 = lists[nlists - 1].nblocks_total;
         return 0;
     }
 };
@@ -287,7 +294,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         }
     }
     // 6. weight gradients: every tensor is one (or a few) K-contractions
-    JobBuilder jb;
+    JobBuilder jb(ws);
     for (int s = 0; s < 3; ++s) {
         const EncOff& e = L.enc[s];
         const SlotPlan& g = P.slot[s];
@@ -356,7 +363,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     MCTSQ_CHECK(jb.part_pos <= P.partial_floats, "internal: partial buffer plan mismatch");
     MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), st));     // alignment pads stay zero
     for (int i = 0; i < jb.nlists; ++i)
-        if (launch_wgrad(jb.lists[i], ws + P.partials, st)) return -1;
+        if (launch_wgrad(jb.lists[i], ws, ws + P.partials, st)) return -1;
     for (int i = 0; i < jb.nlists; ++i)
         if (launch_wgrad_reduce(jb.lists[i], ws + P.partials, d_grad, st)) return -1;
     return 0;
