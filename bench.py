@@ -112,7 +112,7 @@ def cpu_baseline(cfg, ref_net, B, train_B, budget_s=20.0):
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (collected offline with
-    tools/collect_pmc.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM)."""
+    tools/profile_bench.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(path):
         with open(path) as f:
