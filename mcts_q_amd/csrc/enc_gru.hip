@@ -13,18 +13,17 @@ __global__ __launch_bounds__(256) void gru_enc_fwd_kernel(GruFwdArgs args) {
     const GruSlot& s = args.slot[slot];
     __shared__ __attribute__((aligned(16))) GruLds L;
     GruWave<SAVE> g;
-    g.init(s, threadIdx.x & 63, threadIdx.x >> 6);
+    g.bind(threadIdx.x & 63, threadIdx.x >> 6);
+    g.init(s);
     g.stage(s, L, threadIdx.x, row0, args.B, args.Bp);
     __syncthreads();
-    for (int t = 0; t < s.S; ++t) {
-        g.step(s, L, t, row0, args.Bp);
-        __syncthreads();
-    }
-    g.attend(s, L, s.S & 1, s.S - 1, row0, args.Bp);
+    if (SAVE) g.save_window(s, L, threadIdx.x, row0, args.Bp);
+    g.run(s, L, row0, args.Bp);
+    g.attend_flush(s, L, row0, args.Bp);
     g.fin0(L);
-    __syncthreads();
+    g.sync(L);
     g.fin1(L);
-    __syncthreads();
+    g.sync(L);
     g.fin2(s, L, args.feats + row0 * FEAT + s.out_col, FEAT, row0);
 }
 

@@ -3,44 +3,106 @@
 //
 // One "group" = 4 waves (256 lanes) advancing one 16-sample tile of one encoder slot; wave wq of the
 // group owns hidden units 16wq..16wq+15.  Per step every wave computes its 3 gate tiles
-// [16 samples x 16 units] = [x_t | h_{t-1}] . [W_ih | W_hh]^T with v_mfma_f32_16x16x4_f32 (exact fp32),
-// W fragments resident in VGPRs, h exchanged through a double-buffered LDS tile (one barrier per
-// step, issued by the caller).  The softmax over time is evaluated online (running max / sum, in
-// base 2) so no [S,16,64] history is kept on chip.  Reference: dqn_per.py:58-77.
+// [16 samples x 16 units] = [x_t | h_{t-1}] . [W_ih | W_hh]^T.  The input projection (K <= 8) uses
+// v_mfma_f32_16x16x4_f32 (exact fp32).  The recurrent product (K = 64) uses the 16x-faster bf16
+// matrix instruction on a three-way split of both operands: every fp32 value is the exact sum of
+// three bf16 numbers (hi + mid + lo, 8 mantissa bits each), and the six largest of the nine cross
+// products are accumulated in fp32 -- the three dropped ones are below 2^-23 of the product, i.e.
+// under one fp32 ulp; measured error against an fp64 evaluation is smaller than that of a plain
+// fp32 fma chain (tests/test_gpu_qnet.py).  W fragments (pre-split) stay resident in VGPRs, h is
+// split by the lane that produces it and exchanged through double-buffered LDS planes.  The four waves of
+// a group synchronise through an arrival counter in LDS (GruWave::sync), NOT the workgroup barrier,
+// so groups of different window length that share a workgroup advance independently and the short
+// windows fill the issue gaps of the long one.  The attention pooling trails the recurrence by two
+// steps so that all of its VALU / LDS work sits under the MFMA chains; the softmax over time is
+// evaluated online (running max / sum, in base 2) so no [S,16,64] history is kept on chip.
+// Reference: dqn_per.py:58-77.
 #pragma once
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
+#ifndef MCTSQ_EXP
+#define MCTSQ_EXP 0      // timing-ablation bit mask (tools/exp_run.sh); 0 in the product build
+#endif
+
 namespace mctsq {
 
-constexpr int HLD = 68;     // LDS row stride of the h tile (floats): 64 + 4 keeps b128 reads aligned
+constexpr int HLD = 72;     // LDS row stride of an h plane (bf16 elements): 144 B keeps b128 reads conflict-free
 constexpr int XLD = 132;    // LDS row stride of the staged window: >= S * (4 or 8)
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// D(16x16) += A(16x32) * B(32x16) on bf16 inputs, fp32 accumulate.  Lane l supplies A[row l&15][k = 8(l>>4)+e]
+// and B[k = 8(l>>4)+e][col l&15], e = 0..7 packed two per register; D layout as mfma16.
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// x = hi + mid + lo exactly, each part a bf16 (by truncation: every part takes the next 8 mantissa bits)
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    lo = __float_as_uint(r2) & 0xffff0000u;
+}
+// 8 consecutive fp32 -> three packed bf16x8 planes (element e in bits 16(e&1) of word e>>1)
+__device__ __forceinline__ void split8(const float4& x0, const float4& x1, u32x4& hi, u32x4& mid, u32x4& lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(x[2 * p], h0, m0, l0);
+        split3(x[2 * p + 1], h1, m1, l1);
+        hi[p] = (h0 >> 16) | h1; mid[p] = (m0 >> 16) | m1; lo[p] = (l0 >> 16) | l1;
+    }
+}
+
 struct GruLds {             // per-group LDS carve-out
-    float hbuf[2][TILE * HLD];
+    unsigned short hb[3][2][TILE * HLD];   // h planes (hi, mid, lo) x double buffer, bf16 bits
     float xs[TILE * XLD];
     float spart[2][4][TILE];
+    float dump[4][64 * 4];  // write-only sink of the non-publishing lanes (GruWave::publish)
     float red[2][4][TILE];
+    unsigned arrivals;      // monotonically increasing: +1 per wave per sync point
+    unsigned pad_[3];
 };
+
+// Arrival-counter synchronisation of the 4 waves of one group.  `target` = 4 * (sync points so far).
+// Every wave of a workgroup is resident, so the spin always terminates.
+__device__ __forceinline__ void group_sync(unsigned* ctr, unsigned target, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this wave's LDS writes are done
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 template <bool SAVE>
 struct GruWave {
-    float4 wr[4], wz[4], wn[4];     // W_hh[g*64 + j][q*16 .. q*16+15]
+    u32x4 whi[3][2], wmid[3][2], wlo[3][2];   // W_hh[g*64 + j][32c + 8q .. +7], gate g, K chunk c, split
     float wir[2], wiz[2], win[2];   // W_ih[g*64 + j][q (+4)], zero padded
     float br, bz, bin, bhn, awj, ab;
-    float h[4], att[4], mrun[4], lrun[4];
+    float h[4], hp[4], att[4], mrun[4], lrun[4];
     float pooled[4], mean[4], rstd[4];
     int lane, wq, jl, q, j, FP;
+    unsigned nsync;
 
-    __device__ __forceinline__ void init(const GruSlot& s, int lane_, int wq_) {
+    __device__ __forceinline__ void bind(int lane_, int wq_) {
         lane = lane_; wq = wq_; jl = lane & 15; q = lane >> 4; j = 16 * wq + jl;
+        nsync = 0;
+    }
+    // weights and running sums of one window (a wave may run several windows one after another)
+    __device__ __forceinline__ void init(const GruSlot& s) {
         const int F = s.F;
         FP = F > 4 ? 8 : 4;
-        const float4* pr = reinterpret_cast<const float4*>(s.whh + (int64_t)(0 * E + j) * E + q * 16);
-        const float4* pz = reinterpret_cast<const float4*>(s.whh + (int64_t)(1 * E + j) * E + q * 16);
-        const float4* pn = reinterpret_cast<const float4*>(s.whh + (int64_t)(2 * E + j) * E + q * 16);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { wr[c] = pr[c]; wz[c] = pz[c]; wn[c] = pn[c]; }
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float4* pw = reinterpret_cast<const float4*>(s.whh + (int64_t)(g * E + j) * E + 32 * c + 8 * q);
+                split8(pw[0], pw[1], whi[g][c], wmid[g][c], wlo[g][c]);
+            }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int k = q + 4 * ks;
@@ -53,90 +115,199 @@ struct GruWave {
         bin = s.bih[2 * E + j]; bhn = s.bhh[2 * E + j];
         awj = s.aw[j] * LOG2E; ab = s.ab[0] * LOG2E;          // softmax evaluated in base 2
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = 0.0f; att[r] = 0.0f; lrun[r] = 0.0f; mrun[r] = -INFINITY; }
+        for (int r = 0; r < 4; ++r) { h[r] = 0.0f; hp[r] = 0.0f; att[r] = 0.0f; lrun[r] = 0.0f; mrun[r] = -1e30f; }
     }
 
-    // cooperative over the group's 256 lanes (gtid): xs[i][t*FP + f] (zero padded), hbuf[0] = 0
-    __device__ __forceinline__ void stage(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t B, int64_t Bp) {
-        const int S = s.S, F = s.F, Fd = s.Fd, SF = S * FP;
-        for (int idx = gtid; idx < TILE * SF; idx += 256) {
-            const int i = idx / SF, rem = idx - i * SF, t = rem / FP, f = rem - t * FP;
-            float v = 0.0f;
-            if (row0 + i < B && f < F)
-                v = f < Fd ? s.x[(row0 + i) * (int64_t)(S * Fd) + t * Fd + f] : time_feature(s.tf, t, f - Fd);
-            L.xs[i * XLD + rem] = v;
-            if (SAVE && f < 8) s.sv_x[((int64_t)t * Bp + row0 + i) * 8 + f] = v;
-        }
-        if (SAVE) {
-            if (FP == 4)
-                for (int idx = gtid; idx < TILE * S * 4; idx += 256) {
-                    const int i = idx / (S * 4), rem = idx - i * (S * 4), t = rem >> 2, f = 4 + (rem & 3);
-                    s.sv_x[((int64_t)t * Bp + row0 + i) * 8 + f] = 0.0f;
+    __device__ __forceinline__ void sync(GruLds& L) {
+        nsync += 4;
+        if (!(MCTSQ_EXP & 4)) group_sync(&L.arrivals, nsync, lane);
+    }
+
+    // cooperative over the group's 256 lanes (gtid): xs[i][t*FP + f] (zero padded), h planes of buffer 0 = 0.
+    // The tile's 16 windows are one contiguous run of 16*S*Fd floats: every lane issues all its
+    // loads before the first use, so staging costs one memory round trip.  The caller follows with
+    // a WORKGROUP barrier (it also publishes the zeroed arrival counter).
+    __device__ __forceinline__ void stage(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t B, int64_t Bp,
+                                          bool first = true) {
+        const int S = s.S, F = s.F, Fd = s.Fd, SFd = S * Fd, sh = FP == 8 ? 3 : 2;
+        const int n = TILE * SFd;                             // <= 16 * 32 * 8 = 4096 = 16 per lane
+        const float* src = s.x + row0 * (int64_t)SFd;
+        const int64_t lim = (B - row0) * (int64_t)SFd;        // floats present in the batch
+        float v[4];
+        for (int e0 = 0; e0 < n; e0 += 1024) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 + gtid;
+                v[u] = (e < n && e < lim) ? src[e] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 + gtid;
+                if (e < n) {
+                    const int i = e / SFd, rem = e - i * SFd, t = rem / Fd, f = rem - t * Fd;
+                    L.xs[i * XLD + (t << sh) + f] = v[u];
                 }
-            for (int idx = gtid; idx < TILE * E; idx += 256) s.sv_h[row0 * E + idx] = 0.0f;   // h_{-1}
+            }
         }
-        for (int idx = gtid; idx < TILE * HLD; idx += 256) L.hbuf[0][idx] = 0.0f;
+        // columns Fd .. FP-1: time features of the non-_per flavour, then zero padding
+        const int npad = FP - Fd;
+        for (int idx = gtid; idx < TILE * S * npad; idx += 256) {
+            const int i = idx / (S * npad), rem = idx - i * (S * npad), t = rem / npad, f = Fd + rem - t * npad;
+            L.xs[i * XLD + (t << sh) + f] = (f < F && row0 + i < B) ? time_feature(s.tf, t, f - Fd) : 0.0f;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            for (int idx = gtid; idx < TILE * HLD / 2; idx += 256) reinterpret_cast<unsigned*>(L.hb[pl][0])[idx] = 0u;
+        if (first && gtid == 0) L.arrivals = 0;
+        if (SAVE)
+            for (int idx = gtid; idx < TILE * E; idx += 256) s.sv_h[row0 * E + idx] = 0.0f;   // h_{-1}
+    }
+    // training record of the staged window (time-major, 8 columns); call after the barrier
+    __device__ __forceinline__ void save_window(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t Bp) {
+        const int S = s.S, sh = FP == 8 ? 3 : 2;
+        for (int idx = gtid; idx < TILE * S * 8; idx += 256) {
+            const int i = idx / (S * 8), rem = idx - i * (S * 8), t = rem >> 3, f = rem & 7;
+            s.sv_x[((int64_t)t * Bp + row0 + i) * 8 + f] = f < FP ? L.xs[i * XLD + (t << sh) + f] : 0.0f;
+        }
     }
 
-    // fold h (= h_t, its score parts are in spart[buf]) into the running attention sums
-    __device__ __forceinline__ void attend(const GruSlot& s, GruLds& L, int buf, int t, int64_t row0, int64_t Bp) {
+    // ---- attention pooling, kept OFF the recurrence's critical path ---------------------------
+    // The score of h_t needs all 64 units of a row, i.e. all four waves.  Each wave publishes the
+    // partial sums of its 16 units one step late (during step t+1, under the MFMA chain) and folds
+    // h_t into the running softmax sums two steps late (during step t+2, when the partials are
+    // visible behind sync t+1).  spart is indexed by step parity: step t writes parity (t-1)&1 and
+    // reads parity t&1; a wave cannot run more than one sync ahead, and its reads are complete
+    // before it arrives (the release fence drains lgkmcnt), so the two never collide.
+    __device__ __forceinline__ void publish(GruLds& L, int par) {
+        float4 ps;
+        ps.x = row16_sum(awj * h[0]); ps.y = row16_sum(awj * h[1]);
+        ps.z = row16_sum(awj * h[2]); ps.w = row16_sum(awj * h[3]);
+        // one lane per row group stores; the others write their (identical) sums to a dump slot of
+        // their own, which keeps the instruction stream branch-free for the interleaving below
+        float* dst = jl == 0 ? &L.spart[par][wq][4 * q] : &L.dump[wq][lane * 4];
+        *reinterpret_cast<float4*>(dst) = ps;
+    }
+    // online softmax update of row r with score sc (log2 units), e = exp2(-|sc - mrun|): one of the
+    // two rescale factors is always exp2(0) = 1.  mrun starts at -1e30 (finite): a score of -inf
+    // (no step yet) leaves the sums untouched and the first real score resets them
+    __device__ __forceinline__ void fold(float sc, float e, float hv, int r) {
+        const bool up = sc > mrun[r];
+        const float c_old = up ? e : 1.0f, c_new = up ? 1.0f : e;
+        att[r] = att[r] * c_old + c_new * hv;
+        lrun[r] = lrun[r] * c_old + c_new;
+        mrun[r] = up ? sc : mrun[r];
+    }
+    // fold hv (= h_t of this wave's units, whose score parts are in sp) into the running sums
+    __device__ __forceinline__ void attend(const GruSlot& s, const float4 (&sp)[4], const float (&hv)[4], bool live,
+                                           int t, int64_t row0, int64_t Bp) {
+        const float p[4][4] = {{sp[0].x, sp[0].y, sp[0].z, sp[0].w}, {sp[1].x, sp[1].y, sp[1].z, sp[1].w},
+                               {sp[2].x, sp[2].y, sp[2].z, sp[2].w}, {sp[3].x, sp[3].y, sp[3].z, sp[3].w}};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = 4 * q + r;
-            const float sc = ((L.spart[buf][0][i] + L.spart[buf][1][i]) + (L.spart[buf][2][i] + L.spart[buf][3][i])) + ab;
-            if (SAVE && wq == 0 && jl == 0) s.sv_score[(int64_t)t * Bp + row0 + i] = sc;   // log2 units
-            // online softmax: one of the two rescale factors is always exp2(0) = 1
-            const float d = sc - mrun[r];                     // +inf on the first step
-            const float e = fast_exp2(-fabsf(d));             // exp2(-inf) = 0
-            const bool up = d > 0.0f;
-            const float c_old = up ? e : 1.0f, c_new = up ? 1.0f : e;
-            att[r] = att[r] * c_old + c_new * h[r];
-            lrun[r] = lrun[r] * c_old + c_new;
-            mrun[r] = up ? sc : mrun[r];
+            float sc = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) + ab;
+            if (SAVE && live && wq == 0 && jl == 0) s.sv_score[(int64_t)t * Bp + row0 + 4 * q + r] = sc;   // log2 units
+            sc = live ? sc : -INFINITY;
+            fold(sc, fast_exp2(-fabsf(sc - mrun[r])), hv[r], r);
         }
     }
+    __device__ __forceinline__ void load_spart(GruLds& L, int par, float4 (&sp)[4]) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sp[w] = *reinterpret_cast<const float4*>(&L.spart[par][w][4 * q]);
+    }
+    // the whole recurrence: S steps, each followed by the group sync
+    __device__ __forceinline__ void run(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
+        if (FP == 8)
+            for (int t = 0; t < s.S; ++t) { step<true>(s, L, t, row0, Bp); sync(L); }
+        else
+            for (int t = 0; t < s.S; ++t) { step<false>(s, L, t, row0, Bp); sync(L); }
+    }
+    // after the loop: h = h_{S-1}, hp = h_{S-2}; two more folds, one sync between them
+    __device__ __forceinline__ void attend_flush(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
+        const int S = s.S;
+        float4 sp[4];
+        publish(L, (S - 1) & 1);
+        load_spart(L, S & 1, sp);
+        attend(s, sp, hp, S >= 2, S - 2, row0, Bp);
+        sync(L);
+        load_spart(L, (S - 1) & 1, sp);
+        attend(s, sp, h, true, S - 1, row0, Bp);
+    }
 
-    // one recurrence step; the caller issues the barrier afterwards
+    // one recurrence step; the caller follows with sync()
+    template <bool FP8>
     __device__ __forceinline__ void step(const GruSlot& s, GruLds& L, int t, int64_t row0, int64_t Bp) {
         const int cur = t & 1, nxt = cur ^ 1;
-        const float4* ha = reinterpret_cast<const float4*>(&L.hbuf[cur][(lane & 15) * HLD + q * 16]);
-        const float4 a0 = ha[0], a1 = ha[1], a2 = ha[2], a3 = ha[3];
-        const float* xa = &L.xs[(lane & 15) * XLD + t * FP + q];
+        // A fragments of h_{t-1}: plane pl, K chunk c -> 8 bf16 of row lane&15 at k = 32c + 8q
+        u32x4 ah[2], am[2], al[2];
+        {
+            const int o = (lane & 15) * HLD + 8 * q;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                ah[c] = *reinterpret_cast<const u32x4*>(&L.hb[0][cur][o + 32 * c]);
+                am[c] = *reinterpret_cast<const u32x4*>(&L.hb[1][cur][o + 32 * c]);
+                al[c] = *reinterpret_cast<const u32x4*>(&L.hb[2][cur][o + 32 * c]);
+            }
+        }
+        const float* xa = &L.xs[(lane & 15) * XLD + t * (FP8 ? 8 : 4) + q];
         const float x0 = xa[0];
-        f32x4 accr = {0, 0, 0, 0}, accz = {0, 0, 0, 0}, accn = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
+        const float x1 = FP8 ? xa[4] : 0.0f;
+        float4 sp[4];
+        load_spart(L, cur, sp);
+        f32x4 accr = {0, 0, 0, 0}, accz = {0, 0, 0, 0}, accn = {0, 0, 0, 0}, accm = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
+        // input projection, exact fp32
         accr = mfma16(x0, wir[0], accr); accz = mfma16(x0, wiz[0], accz); acci = mfma16(x0, win[0], acci);
-        if (FP == 8) {                                        // wave-uniform
-            const float x1 = xa[4];
+        if (FP8) {
             accr = mfma16(x1, wir[1], accr); accz = mfma16(x1, wiz[1], accz); acci = mfma16(x1, win[1], acci);
         }
-        if (t > 0) attend(s, L, cur, t - 1, row0, Bp);
-#define GRU_STEP4(A, C)                                                                                      \
-        accr = mfma16(A.x, wr[C].x, accr); accz = mfma16(A.x, wz[C].x, accz); accn = mfma16(A.x, wn[C].x, accn); \
-        accr = mfma16(A.y, wr[C].y, accr); accz = mfma16(A.y, wz[C].y, accz); accn = mfma16(A.y, wn[C].y, accn); \
-        accr = mfma16(A.z, wr[C].z, accr); accz = mfma16(A.z, wz[C].z, accz); accn = mfma16(A.z, wn[C].z, accn); \
-        accr = mfma16(A.w, wr[C].w, accr); accz = mfma16(A.w, wz[C].w, accz); accn = mfma16(A.w, wn[C].w, accn);
-        GRU_STEP4(a0, 0) GRU_STEP4(a1, 1) GRU_STEP4(a2, 2) GRU_STEP4(a3, 3)
-#undef GRU_STEP4
-        float ps[4];
+        // recurrent product: six split terms per K chunk, smallest first; r and z chains alternate
+#define T6(ACC0, ACC1, G0, G1, C)                                                              \
+        ACC0 = mfma_bf(al[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(al[C], whi[G1][C], ACC1);    \
+        ACC0 = mfma_bf(ah[C], wlo[G0][C], ACC0);  ACC1 = mfma_bf(ah[C], wlo[G1][C], ACC1);    \
+        ACC0 = mfma_bf(am[C], wmid[G0][C], ACC0); ACC1 = mfma_bf(am[C], wmid[G1][C], ACC1);   \
+        ACC0 = mfma_bf(am[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(am[C], whi[G1][C], ACC1);    \
+        ACC0 = mfma_bf(ah[C], wmid[G0][C], ACC0); ACC1 = mfma_bf(ah[C], wmid[G1][C], ACC1);   \
+        ACC0 = mfma_bf(ah[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(ah[C], whi[G1][C], ACC1);
+        if (!(MCTSQ_EXP & 32)) {
+        T6(accr, accz, 0, 1, 0)
+        T6(accr, accz, 0, 1, 1)
+        }
+        if (!(MCTSQ_EXP & 1)) {                               // pooling, two steps behind (see above)
+            publish(L, nxt);                                  // partial scores of h_{t-1} (still in h)
+            attend(s, sp, hp, t >= 2, t >= 2 ? t - 2 : 0, row0, Bp);
+        }
+#undef T6
+        // n gate: K chunk 0 into accn, chunk 1 into accm (two independent chains)
+        if (!(MCTSQ_EXP & 32)) {
+        accn = mfma_bf(al[0], whi[2][0], accn);  accm = mfma_bf(al[1], whi[2][1], accm);
+        accn = mfma_bf(ah[0], wlo[2][0], accn);  accm = mfma_bf(ah[1], wlo[2][1], accm);
+        accn = mfma_bf(am[0], wmid[2][0], accn); accm = mfma_bf(am[1], wmid[2][1], accm);
+        accn = mfma_bf(am[0], whi[2][0], accn);  accm = mfma_bf(am[1], whi[2][1], accm);
+        accn = mfma_bf(ah[0], wmid[2][0], accn); accm = mfma_bf(ah[1], wmid[2][1], accm);
+        accn = mfma_bf(ah[0], whi[2][0], accn);  accm = mfma_bf(ah[1], whi[2][1], accm);
+        }
+        float rg[4], zg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rg[r] = (MCTSQ_EXP & 2) ? accr[r] + br : sigmoid_fast(accr[r] + br);
+            zg[r] = (MCTSQ_EXP & 2) ? accz[r] + bz : sigmoid_fast(accz[r] + bz);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            const float rg = sigmoid_fast(accr[r] + br);
-            const float zg = sigmoid_fast(accz[r] + bz);
-            const float hn = accn[r] + bhn;
-            const float ng = tanh_fast((acci[r] + bin) + rg * hn);
-            const float hnew = ng + zg * (h[r] - ng);
+            const float hn = (accn[r] + accm[r]) + bhn;
+            const float ng = (MCTSQ_EXP & 2) ? (acci[r] + bin) + rg[r] * hn : tanh_fast((acci[r] + bin) + rg[r] * hn);
+            const float hnew = ng + zg[r] * (h[r] - ng);
+            unsigned u0, u1, u2;
+            split3(hnew, u0, u1, u2);
+            L.hb[0][nxt][i * HLD + j] = (unsigned short)(u0 >> 16);
+            L.hb[1][nxt][i * HLD + j] = (unsigned short)(u1 >> 16);
+            L.hb[2][nxt][i * HLD + j] = (unsigned short)(u2 >> 16);
             if (SAVE) {
                 const int64_t o = ((int64_t)t * Bp + row0 + i) * E + j;
-                s.sv_r[o] = rg; s.sv_z[o] = zg; s.sv_n[o] = ng; s.sv_hn[o] = hn; s.sv_h[o + Bp * E] = hnew;
+                s.sv_r[o] = rg[r]; s.sv_z[o] = zg[r]; s.sv_n[o] = ng; s.sv_hn[o] = hn; s.sv_h[o + Bp * E] = hnew;
             }
+            hp[r] = h[r];
             h[r] = hnew;
-            L.hbuf[nxt][i * HLD + j] = hnew;
-            ps[r] = row16_sum(awj * hnew);
-        }
-        if (jl == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L.spart[nxt][wq][4 * q + r] = ps[r];
         }
     }
 

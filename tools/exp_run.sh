@@ -1,0 +1,6 @@
+#!/bin/bash
+# timing of kernel ablation variants (tools/bin/libexp*.so): fused forward only
+for f in mcts_q_amd/lib/libmctsq_hip.so tools/bin/libexp*.so; do
+  echo -n "$f: "
+  MCTSQ_HIP_LIB=$PWD/$f timeout -k 10 100 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-train 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms']*1e3, 'us')"
+done

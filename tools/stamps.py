@@ -14,17 +14,12 @@ x = [torch.rand(B, 25, 1).cuda(), torch.rand(B, 10, 6).cuda(), torch.rand(B, 3, 
 for _ in range(5):
     net(*x)
 torch.cuda.synchronize()
-out = np.zeros(128, dtype=np.int64)
+out = np.zeros(256, dtype=np.int64)
 lib._load().mctsq_debug_stamps.argtypes = [C.c_void_p]
 lib._load().mctsq_debug_stamps(out.ctypes.data)
-st = out[:64].reshape(4, 16)[:, :12]
-it = out[64:]
-print("wave0 per-iteration: work cycles (pre-barrier), barrier wait")
-for i in range(28):
-    prev = it[32 + i - 1] if i else st[1, 0]
-    print(i, it[i] - prev, it[32 + i] - it[i])
-print("ticks (100 MHz s_memtime => x10 ns) per wave: init+stage, gru loop, head")
+st = out[:64].reshape(4, 16)[:, :8]
+print("ticks per wave: first window (init+stage+loop+LN), second window (group 1), head")
 d = np.diff(st, axis=0)
-for w in range(12):
+for w in range(8):
     print(w, d[:, w], "total", st[3, w] - st[0, w])
 print("kernel span (all waves):", st[3].max() - st[0].min())
