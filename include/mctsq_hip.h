@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MCTSQ_ABI_VERSION 1
+#define MCTSQ_ABI_VERSION 2
 
 /* encoder kinds (dqn_per.py:181-203) */
 enum { MCTSQ_ENC_CONV = 1, MCTSQ_ENC_GRU = 2, MCTSQ_ENC_TRANSFORMER = 3, MCTSQ_ENC_MLP = 4 };
@@ -85,6 +85,21 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
                        const float* d_process, const float* d_gas, int64_t B, float* d_q,
                        float* d_vmax, int32_t* d_argmax, float* d_prior, void* d_ws,
                        int64_t ws_bytes, void* stream, void* ev_encoders_done);
+
+/* ---- prepared weights.  The GRU recurrence multiplies by W_hh through the bf16 matrix instruction
+ * on an exact three-way split of every fp32 weight.  mctsq_q_forward splits
+ * the weights into its workspace on every call; a caller whose parameters stay fixed over many
+ * evaluations (MCTS leaf evaluation between learner steps, mctsq_config_mcts_per.py:291-296,
+ * 367-370) prepares them once and calls mctsq_q_forward_prepared.  d_prep: mctsq_q_prepared_bytes
+ * bytes, 16-byte aligned; it must be re-prepared after every change of d_params.  No reference
+ * counterpart (torch keeps one weight tensor). */
+int64_t mctsq_q_prepared_bytes(const mctsq_net_desc* net);
+int mctsq_q_prepare(const mctsq_net_desc* net, const float* d_params, void* d_prep, int64_t prep_bytes,
+                    void* stream);
+int mctsq_q_forward_prepared(const mctsq_net_desc* net, const float* d_params, const void* d_prep,
+                             const float* d_price, const float* d_process, const float* d_gas,
+                             int64_t B, float* d_q, float* d_vmax, int32_t* d_argmax, float* d_prior,
+                             void* d_ws, int64_t ws_bytes, void* stream, void* ev_encoders_done);
 
 /* ---- PER-DQN learner step on an already gathered batch: DQNModel.update (dqn_per.py:455-472)
  * = policy forward (activations kept), target forward + max, TD target and IS-weighted MSE,

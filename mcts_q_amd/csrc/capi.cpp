@@ -27,13 +27,16 @@ static void fill_gru_slot(GruSlot& g, const EncOff& e, const float* params, cons
     }
 }
 
-void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                   int64_t Bp, float* feats, const SlotSave* sv) {
+void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, const void* prep,
+                   const float* const x[3], int64_t B, int64_t Bp, float* feats, const SlotSave* sv) {
     memset(&ga, 0, sizeof(ga));
     ga.B = B; ga.Bp = Bp; ga.feats = feats;
     for (int s = 0; s < 3; ++s)
-        if (L.enc[s].kind == MCTSQ_ENC_GRU)
-            fill_gru_slot(ga.slot[ga.nslots++], L.enc[s], params, x[s], s, sv ? &sv[s] : nullptr);
+        if (L.enc[s].kind == MCTSQ_ENC_GRU) {
+            fill_gru_slot(ga.slot[ga.nslots], L.enc[s], params, x[s], s, sv ? &sv[s] : nullptr);
+            ga.slot[ga.nslots].wprep = prep ? (const char*)prep + ga.nslots * GRU_PREP_BYTES : nullptr;
+            ++ga.nslots;
+        }
 }
 
 void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
@@ -72,7 +75,21 @@ int64_t forward_ws_floats(const NetLayout& L, int64_t Bp) {
     int64_t n = Bp * FEAT;
     for (int s = 0; s < 2; ++s)
         if (L.enc[s].kind == MCTSQ_ENC_TRANSFORMER) n += 2 * tf_padded_tokens(Bp, L.enc[s].S) * E;
-    return n;
+    return n + prepared_bytes(L) / (int64_t)sizeof(float);
+}
+
+int64_t prepared_bytes(const NetLayout& L) {
+    int n = 0;
+    for (int s = 0; s < 3; ++s) n += L.enc[s].kind == MCTSQ_ENC_GRU;
+    return n * GRU_PREP_BYTES;
+}
+
+int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_t st) {
+    const float* whh[3] = {nullptr, nullptr, nullptr};
+    int n = 0;
+    for (int s = 0; s < 3; ++s)
+        if (L.enc[s].kind == MCTSQ_ENC_GRU) whh[n++] = params + L.enc[s].gru.whh;
+    return launch_gru_prepare(whh, n, prep, st);
 }
 
 void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
@@ -102,12 +119,17 @@ void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* 
 
 // TripleEncoderDQN.forward (dqn_per.py:232-236) + leaf epilogue.  `sv` != NULL keeps the
 // activations the backward pass needs (training) and always takes the per-encoder kernels.
-int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
-                 float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
+int forward_impl(const NetLayout& L, const float* params, const void* prep, const float* const x[3], int64_t B,
+                 int64_t Bp, float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
                  void* ev_encoders_done) {
     float* feats = ws;
+    if (!prep && prepared_bytes(L) > 0) {                     // the workspace's tail holds the split weights
+        void* own = ws + forward_ws_floats(L, Bp) - prepared_bytes(L) / (int64_t)sizeof(float);
+        if (prepare_impl(L, params, own, st)) return -1;
+        prep = own;
+    }
     GruFwdArgs ga;
-    fill_gru_args(ga, L, params, x, B, Bp, feats, sv);
+    fill_gru_args(ga, L, params, prep, x, B, Bp, feats, sv);
     ConvFwdArgs ca;
     fill_conv_args(ca, L, params, x, B, Bp, feats, sv);
     MlpArgs ma;
@@ -204,7 +226,43 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
     MCTSQ_CHECK(((uintptr_t)d_ws & 15) == 0, "workspace must be 16-byte aligned");
     const float* x[3] = {d_price, d_process, d_gas};
     HeadOut out{d_q, d_vmax, d_argmax, d_prior};
-    return forward_impl(L, d_params, x, B, Bp, (float*)d_ws, out, nullptr, nullptr, (hipStream_t)stream,
+    return forward_impl(L, d_params, nullptr, x, B, Bp, (float*)d_ws, out, nullptr, nullptr, (hipStream_t)stream,
+                        ev_encoders_done);
+}
+
+int64_t mctsq_q_prepared_bytes(const mctsq_net_desc* net) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    return prepared_bytes(L);
+}
+
+int mctsq_q_prepare(const mctsq_net_desc* net, const float* d_params, void* d_prep, int64_t prep_bytes, void* stream) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    if (prepared_bytes(L) == 0) return 0;
+    MCTSQ_CHECK(d_params && d_prep && prep_bytes >= prepared_bytes(L), "NULL pointer or prepared buffer too small");
+    MCTSQ_CHECK(((uintptr_t)d_prep & 15) == 0, "prepared buffer must be 16-byte aligned");
+    return prepare_impl(L, d_params, d_prep, (hipStream_t)stream);
+}
+
+int mctsq_q_forward_prepared(const mctsq_net_desc* net, const float* d_params, const void* d_prep,
+                             const float* d_price, const float* d_process, const float* d_gas, int64_t B, float* d_q,
+                             float* d_vmax, int32_t* d_argmax, float* d_prior, void* d_ws, int64_t ws_bytes,
+                             void* stream, void* ev_encoders_done) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_params && d_price && d_process && d_gas && d_q, "NULL device pointer");
+    MCTSQ_CHECK(d_prep || prepared_bytes(L) == 0, "NULL prepared-weights pointer");
+    MCTSQ_CHECK(((uintptr_t)d_prep & 15) == 0, "prepared buffer must be 16-byte aligned");
+    const int64_t Bp = round_up(B, TILE);
+    MCTSQ_CHECK(d_ws && ws_bytes >= forward_ws_floats(L, Bp) * (int64_t)sizeof(float),
+                "workspace too small (%lld bytes)", (long long)ws_bytes);
+    MCTSQ_CHECK(((uintptr_t)d_ws & 15) == 0, "workspace must be 16-byte aligned");
+    const float* x[3] = {d_price, d_process, d_gas};
+    HeadOut out{d_q, d_vmax, d_argmax, d_prior};
+    return forward_impl(L, d_params, d_prep, x, B, Bp, (float*)d_ws, out, nullptr, nullptr, (hipStream_t)stream,
                         ev_encoders_done);
 }
 

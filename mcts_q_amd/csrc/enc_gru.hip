@@ -27,7 +27,32 @@ __global__ __launch_bounds__(256) void gru_enc_fwd_kernel(GruFwdArgs args) {
     g.fin2(s, L, args.feats + row0 * FEAT + s.out_col, FEAT, row0);
 }
 
+// one thread per (slot, wave, gate, K chunk, lane): 8 consecutive weights -> 3 x 8 bf16
+struct GruPrepArgs { const float* whh[3]; u32x4* out; };
+__global__ __launch_bounds__(256) void gru_prepare_kernel(GruPrepArgs a) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;           // grid = n * 6 blocks of 256
+    const int lane = tid & 63, c = (tid >> 6) & 1, rest = tid >> 7, g = rest % 3, wq = (rest / 3) & 3, slot = rest / 12;
+    const int jl = lane & 15, q = lane >> 4;
+    const float4* pw = reinterpret_cast<const float4*>(a.whh[slot] + (int64_t)(g * E + 16 * wq + jl) * E + 32 * c + 8 * q);
+    u32x4 hi, mid, lo;
+    split8(pw[0], pw[1], hi, mid, lo);
+    u32x4* o = a.out + (int64_t)slot * (GRU_PREP_BYTES / 16) + (((wq * 3 + g) * 2 + c) * 3) * 64 + lane;
+    o[0] = hi; o[64] = mid; o[128] = lo;
+}
+
+int launch_gru_prepare(const float* const whh[3], int n, void* prep, hipStream_t st) {
+    if (n == 0) return 0;
+    GruPrepArgs a;
+    for (int i = 0; i < 3; ++i) a.whh[i] = whh[i < n ? i : 0];
+    a.out = reinterpret_cast<u32x4*>(prep);
+    hipLaunchKernelGGL(gru_prepare_kernel, dim3((unsigned)(n * 6)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int check_gru_args(const GruFwdArgs& args) {
+    for (int i = 0; i < args.nslots; ++i)
+        MCTSQ_CHECK(args.slot[i].wprep && ((uintptr_t)args.slot[i].wprep & 15) == 0, "GRU encoder needs prepared weights");
     for (int i = 0; i < args.nslots; ++i)
         MCTSQ_CHECK(args.slot[i].S * (args.slot[i].F > 4 ? 8 : 4) <= XLD && args.slot[i].F <= MAX_F,
                     "GRU encoder window %dx%d does not fit the staged tile", args.slot[i].S, args.slot[i].F);

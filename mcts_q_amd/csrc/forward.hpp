@@ -27,18 +27,22 @@ struct HeadOut {
     float* prior;
 };
 
-void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                   int64_t Bp, float* feats, const SlotSave* sv);
+void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, const void* prep,
+                   const float* const x[3], int64_t B, int64_t Bp, float* feats, const SlotSave* sv);
 void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
                     int64_t Bp, float* feats, const SlotSave* sv);
 bool fill_mlp_args(MlpArgs& ma, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
                    int64_t Bp, float* feats, const SlotSave* sv);
-// floats of forward scratch: feature rows [Bp][192] + token buffers of the transformer slots
+// floats of forward scratch: feature rows [Bp][192] + token buffers of the transformer slots + the
+// prepared (split) recurrent weights of the GRU slots
 int64_t forward_ws_floats(const NetLayout& L, int64_t Bp);
+int64_t prepared_bytes(const NetLayout& L);
+int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_t st);
 void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
                   int64_t Bp, float* feats, float* hbuf, const SlotSave* sv);
-int forward_impl(const NetLayout& L, const float* params, const float* const x[3], int64_t B, int64_t Bp,
-                 float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
+// prep: prepared weights of `params` (prepare_impl), or NULL to prepare them into the workspace first
+int forward_impl(const NetLayout& L, const float* params, const void* prep, const float* const x[3], int64_t B,
+                 int64_t Bp, float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
                  void* ev_encoders_done);
 
 }  // namespace mctsq

@@ -4,7 +4,7 @@
 //   waves 0-3  the longest window (price, 25 steps), waves 4-7 the other two back to back (10 + 3).
 // Each 4-wave group synchronises through its own LDS arrival counter (gru_core.hpp), not the
 // workgroup barrier: the price recurrence is the critical path and runs at raised issue priority
-// while the shorter windows fill the gaps its gate math and h exchange leave.  Waves 4-7 then fetch
+// while the shorter windows fill the gaps its gate math and h exchange leave.  Waves 0-3 then fetch
 // the head's weight fragments straight into VGPRs while the price recurrence is still running;
 // the feature rows never leave LDS and the head needs no second launch.
 #include "gru_core.hpp"
@@ -18,8 +18,10 @@ constexpr int ALD1 = 128 + 4;    // hidden activation row stride
 __device__ long long g_stamps[4 * 64];
 __device__ long long g_iter[192];
 #define STAMP(k) do { if (blockIdx.x == 0 && lane == 0) g_stamps[(k) * 16 + wave] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WSTAMP(k) do { if (blockIdx.x == 0 && gtid == 0) g_iter[(first ? 0 : 16) + ((gtid != (int)threadIdx.x) ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(k) do {} while (0)
+#define WSTAMP(k) do {} while (0)
 #endif
 
 #ifndef MCTSQ_PRIO
@@ -37,18 +39,24 @@ struct FusedLds {
 template <bool SAVE>
 __device__ __forceinline__ void run_window(GruWave<SAVE>& g, const GruSlot& s, GruLds& G, float* feats, int gtid,
                                            int64_t row0, int64_t B, int64_t Bp, bool first) {
+    WSTAMP(0);
     g.init(s);
     g.stage(s, G, gtid, row0, B, Bp, first);
+    WSTAMP(1);
     if (first) __syncthreads();                       // also publishes the zeroed arrival counters
     else g.sync(G);
+    WSTAMP(2);
     if (SAVE) g.save_window(s, G, gtid, row0, Bp);
     g.run(s, G, row0, Bp);
+    WSTAMP(3);
     g.attend_flush(s, G, row0, Bp);
+    WSTAMP(4);
     g.fin0(G);
     g.sync(G);
     g.fin1(G);
     g.sync(G);
     g.fin2(s, G, feats + s.out_col, FLD, row0);
+    WSTAMP(5);
 }
 
 template <bool SAVE>
@@ -78,12 +86,14 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         run_window<SAVE>(g, ga.slot[sb], G, L.feats, gtid, row0, ga.B, ga.Bp, false);
     }
     __builtin_amdgcn_s_setprio(0);
-    // The GRU registers are dead from here on.  Waves 4..7 fetch the head's weight fragments (two
-    // 16-column tiles of layers 0 and 1 each; wave 4 also the output layer) while the long window is
-    // still stepping: B[k = q*K4 + kk][col] = W[col][k].
-    const int ht = wave - 4;
+    // The GRU registers are dead from here on.  Group 0 finishes first (25 steps against 10 + 3 and a
+    // second staging): its waves fetch the head's weight fragments (two 16-column tiles of layers 0
+    // and 1 each; wave 0 also the output layer) while group 1 is still stepping:
+    // B[k = q*K4 + kk][col] = W[col][k].
+    const int ht = wave;
+    const bool head_wave = wave < 4;
     float4 w0f[2][12], w1f[2][8], w2f[8];
-    if (wave >= 4) {
+    if (head_wave) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const float4* p0 = reinterpret_cast<const float4*>(ha.w[0] + (int64_t)(16 * (ht + 4 * tt) + jl) * FEAT + q * 48);
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
 #pragma unroll
             for (int c = 0; c < 8; ++c) w1f[tt][c] = p1[c];
         }
-        if (wave == 4) {
+        if (wave == 0) {
             const float4* p2 = reinterpret_cast<const float4*>(ha.w[2] + (int64_t)(jl < ha.A ? jl : 0) * 128 + q * 32);
 #pragma unroll
             for (int c = 0; c < 8; ++c) w2f[c] = jl < ha.A ? p2[c] : make_float4(0, 0, 0, 0);
@@ -109,8 +119,8 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         }
     }
 
-    // ---- head layer 0: [16 x 192] . W0^T, two column tiles per wave 4..7 ------------------
-    if (wave >= 4) {
+    // ---- head layer 0: [16 x 192] . W0^T, two column tiles per wave 0..3 ------------------
+    if (head_wave) {
         const float4* xa = reinterpret_cast<const float4*>(&L.feats[(lane & 15) * FLD + q * 48]);
         f32x4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
 #pragma unroll
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     }
     __syncthreads();
     // ---- head layer 1: [16 x 128] . W1^T ---------------------------------------------------
-    if (wave >= 4) {
+    if (head_wave) {
         const float4* xa = reinterpret_cast<const float4*>(&L.act[0][(lane & 15) * ALD1 + q * 32]);
         f32x4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
 #pragma unroll
@@ -165,8 +175,8 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         }
     }
     __syncthreads();
-    // ---- output layer: [16 x 128] . W2^T (A <= 16 columns), wave 4 -------------------------
-    if (wave == 4) {
+    // ---- output layer: [16 x 128] . W2^T (A <= 16 columns), wave 0 -------------------------
+    if (wave == 0) {
         const float4* xa = reinterpret_cast<const float4*>(&L.act[1][(lane & 15) * ALD1 + q * 32]);
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll

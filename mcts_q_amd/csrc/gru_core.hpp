@@ -96,12 +96,14 @@ struct GruWave {
     __device__ __forceinline__ void init(const GruSlot& s) {
         const int F = s.F;
         FP = F > 4 ? 8 : 4;
+        const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep) + (int64_t)wq * (3 * 2 * 3 * 64) + lane;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float4* pw = reinterpret_cast<const float4*>(s.whh + (int64_t)(g * E + j) * E + 32 * c + 8 * q);
-                split8(pw[0], pw[1], whi[g][c], wmid[g][c], wlo[g][c]);
+                whi[g][c] = wp[((g * 2 + c) * 3 + 0) * 64];
+                wmid[g][c] = wp[((g * 2 + c) * 3 + 1) * 64];
+                wlo[g][c] = wp[((g * 2 + c) * 3 + 2) * 64];
             }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {

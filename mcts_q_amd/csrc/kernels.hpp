@@ -8,6 +8,7 @@ namespace mctsq {
 struct GruSlot {
     const float* x;                      // [B][S][Fd]
     const float *wih, *whh, *bih, *bhh, *aw, *ab, *lnw, *lnb;
+    const void* wprep;                   // W_hh split into bf16 planes in fragment order (gru_prepare_kernel)
     int S, Fd, F, tf, out_col;
     // training-time activation record (NULL for inference), Bp = padded batch
     float* sv_h;                         // [S+1][Bp][64]: block 0 = h_{-1} = 0, block t+1 = h_t
@@ -28,6 +29,10 @@ struct GruFwdArgs {
     float* feats;                        // [Bp][192]
 };
 int launch_gru_fwd(const GruFwdArgs& args, bool save, hipStream_t st);
+// W_hh [192][64] fp32 -> three bf16 planes (hi, mid, lo; hi + mid + lo == w exactly) laid out as the
+// recurrence kernels load them: u32x4 [wave 4][gate 3][K chunk 2][plane 3][lane 64]
+constexpr int64_t GRU_PREP_BYTES = 4 * 3 * 2 * 3 * 64 * 16;
+int launch_gru_prepare(const float* const whh[3], int n, void* prep, hipStream_t st);
 
 // ---------------- Conv-attention encoder (dqn_per.py:21-55) ----------------
 struct ConvSlot {

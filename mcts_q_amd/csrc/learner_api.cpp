@@ -202,7 +202,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     {
         const float* x[3] = {d_nprice, d_nprocess, d_ngas};
         HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
-        if (forward_impl(L, d_target_params, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, st, nullptr)) return -1;
+        if (forward_impl(L, d_target_params, nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, st, nullptr)) return -1;
     }
     // 2. policy network on s, activations kept (dqn_per.py:455-457)
     SlotSave sv[3];
@@ -235,7 +235,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     const float* xs[3] = {d_sprice, d_sprocess, d_sgas};
     {
         HeadOut out{ws + P.q_p, nullptr, nullptr, nullptr};
-        if (forward_impl(L, d_params, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr)) return -1;
+        if (forward_impl(L, d_params, nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr)) return -1;
     }
     // 3. TD target, IS-weighted MSE, dLoss/dQ, new priorities (dqn_per.py:464-467, 474)
     {
@@ -265,7 +265,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         for (int i = 0; i < ca.nslots; ++i) cb.slot[i] = ca.slot[i];
         if (launch_conv_bwd(cb, st)) return -1;
         GruFwdArgs ga;
-        fill_gru_args(ga, L, d_params, xs, B, Bp, ws + P.feats_p, sv);
+        fill_gru_args(ga, L, d_params, nullptr, xs, B, Bp, ws + P.feats_p, sv);
         GruBwdArgs gb;
         memset(&gb, 0, sizeof(gb));
         gb.nslots = ga.nslots; gb.Bp = Bp; gb.dfeat = ws + P.dfeat;

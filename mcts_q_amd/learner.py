@@ -89,7 +89,10 @@ class DeviceLearner:
             ptr(self.target.flat), n, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
             self.max_grad_norm, -1.0 if tau is None else float(tau), ptr(self.grad_norm),
             ptr(self._small), self._small.numel(), self._st()))
+        self.policy.mark_dirty()
+        self.target.mark_dirty()
 
     def update_target(self, tau: float = 1.0):
         lib.check(lib.mctsq_polyak(ptr(self.policy.flat), ptr(self.target.flat), self.spec.n_flat, float(tau),
                                    self._st()))
+        self.target.mark_dirty()

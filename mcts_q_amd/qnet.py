@@ -33,6 +33,22 @@ class DeviceQNet:
                                                                device=self.device)
         assert self.flat.numel() == self.n_flat and self.flat.is_contiguous()
         self._ws = None
+        # recurrent GRU weights split into bf16 planes (mctsq_q_prepare); rebuilt whenever the flat buffer
+        # changed: torch's version counter sees in-place torch ops (also through views()), the library's own
+        # kernels (Adam, Polyak) do not, so their callers use mark_dirty()
+        nprep = lib.check(lib.mctsq_q_prepared_bytes(C.byref(self.desc)))
+        self._prep = torch.empty(max(nprep, 16), dtype=torch.uint8, device=self.device)
+        self._prep_version = None
+
+    def mark_dirty(self):
+        self._prep_version = None
+
+    def _prepared(self):
+        if self._prep_version != self.flat._version:
+            lib.check(lib.mctsq_q_prepare(C.byref(self.desc), ptr(self.flat), ptr(self._prep), self._prep.numel(),
+                                          _stream_ptr(self.device)))
+            self._prep_version = self.flat._version
+        return self._prep
 
     # ---- parameters -------------------------------------------------------------------
     def load_state_dict(self, sd):
@@ -75,10 +91,10 @@ class DeviceQNet:
                        prior=torch.empty(B, A, dtype=torch.float32, device=self.device) if want_prior else None)
         nbytes = lib.check(lib.mctsq_q_forward_workspace_bytes(C.byref(self.desc), B))
         ws = self._workspace(nbytes)
-        lib.check(lib.mctsq_q_forward_ex(C.byref(self.desc), ptr(self.flat), ptr(price), ptr(process), ptr(gas),
-                                         B, ptr(out["q"]), ptr(out["vmax"]), ptr(out["argmax"]),
-                                         ptr(out.get("prior")), ptr(ws), ws.numel(), _stream_ptr(self.device),
-                                         mid_event))
+        lib.check(lib.mctsq_q_forward_prepared(C.byref(self.desc), ptr(self.flat), ptr(self._prepared()), ptr(price),
+                                               ptr(process), ptr(gas), B, ptr(out["q"]), ptr(out["vmax"]), ptr(out["argmax"]),
+                                               ptr(out.get("prior")), ptr(ws), ws.numel(),
+                                               _stream_ptr(self.device), mid_event))
         return out
 
     __call__ = forward
