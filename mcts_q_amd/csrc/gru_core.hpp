@@ -218,10 +218,15 @@ struct GruWave {
     }
     // the whole recurrence: S steps, each followed by the group sync
     __device__ __forceinline__ void run(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
-        if (FP == 8)
+        // unrolled by two: the double-buffer parity becomes a constant and h / hp swap roles
+        // without register copies
+        if (FP == 8) {
+#pragma unroll 2
             for (int t = 0; t < s.S; ++t) { step<true>(s, L, t, row0, Bp); sync(L); }
-        else
+        } else {
+#pragma unroll 2
             for (int t = 0; t < s.S; ++t) { step<false>(s, L, t, row0, Bp); sync(L); }
+        }
     }
     // after the loop: h = h_{S-1}, hp = h_{S-2}; two more folds, one sync between them
     __device__ __forceinline__ void attend_flush(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
