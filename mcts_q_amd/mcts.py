@@ -1,0 +1,243 @@
+"""MCTS_Q agent: host-side mirror of the reference's `MCTSQ` and `MCTSQConfiguration`
+(/root/reference/src/mctsq_config_mcts_per.py:33-466, 555-651) on top of the lock-step tree driver
+(treesearch.py) and the HIP learner (dqn.py).  Same constructor arguments, attributes and methods
+(`learn`, `predict`, `save`, `load`, `test`), same cadence of replay pushes / updates / Polyak target
+syncs / sub-tree reuse in `learn`; the network calls go through `DQNModel.policy_net.evaluate_leaves`
+(one launch per search iteration) instead of a scripted torch module.
+
+`LockstepAgent` is the many-environment form the north star asks for: K environments / trees per process
+advance one search iteration together, so each iteration is ONE leaf batch of K states (BASELINE config
+5: 512 trees per GPU).  It has no counterpart in the reference (one tree, B = 1 calls)."""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+import yaml
+
+from .dqn import DQNModel
+from .leafbatch import split_rows
+from .treesearch import LockstepMCTS
+
+
+class MCTSQConfiguration:
+    """config/config_mctsq.yaml -> attributes, and the run-id string (mcts_per.py:555-651)."""
+
+    HYPER = (('Iterations', "_it", 'iterations'), ('PUCT Initial Exploration', "_pu", 'c_init'),
+             ('PUCT Exploration Increase', "_pi", 'c_base'), ('Max Tree depth', "_md", 'maximum_depth'),
+             ('Learning rate', "_al", 'learning_rate'), ('Discount factor', "_ga", 'discount_factor'),
+             ('Replay buffer size', "_rb", 'buffer_size'), ('Batch size', "_bs", 'batch_size'),
+             ('Hidden layers', "_hl", 'hidden_layers'), ('Hidden units', "_hu", 'hidden_units'),
+             ('Activation function', "_af", 'activation'), ('Softupdate factor', "_ta", 'tau'),
+             ('Process data sequence', "_sq", 'seq_length'), ('Embedding dimensions', "_ed", 'embed_dim'),
+             ('Price encoder type', "_ee", 'price_encoder_type'), ('Process encoder type', "_pe", 'process_encoder_type'),
+             ('Gas EUA encoder type', "_ge", 'gas_eua_encoder_type'))
+
+    def __init__(self, path: str = "config/config_mctsq.yaml", values: dict | None = None) -> None:
+        if values is None:
+            with open(path, "r", encoding="utf-8") as f:
+                values = yaml.safe_load(f)
+        self.__dict__.update(values)
+        self.rl_alg_hyp = values
+        self.str_alg = ""
+        self.hyper = {name: {'abb': abb, 'var': var} for name, abb, var in self.HYPER}
+
+    def get_hyper(self) -> str:
+        print("    > MCTS_Q algorithm : >>> <<<")
+        for name, _, _ in self.HYPER:
+            self.hyp_print(name)
+        print(' ')
+        return self.str_alg
+
+    def hyp_print(self, hyp_name: str) -> None:
+        if hyp_name not in self.hyper:
+            raise ValueError(f"Specified hyperparameter ({hyp_name}) is not part of the implemented settings!")
+        abb, val = self.hyper[hyp_name]['abb'], self.rl_alg_hyp[self.hyper[hyp_name]['var']]
+        n = len(hyp_name)
+        tabs = "" if n > 32 else "\t" if n > 22 else "\t\t" if n > 15 else "\t\t\t"
+        print(f"         {hyp_name} ({abb}):{tabs} {val}")
+        self.str_alg += abb + str(val)
+
+
+def _device_evaluator(policy_net):
+    """rows fp32 [n, 91] (host) -> (vmax [n], prior [n, A]) through ONE launch of the HIP forward."""
+    dev = policy_net.device
+
+    def evaluate(rows):
+        t = torch.from_numpy(np.ascontiguousarray(rows)).to(dev, non_blocking=True)
+        out = policy_net.evaluate_leaves(*split_rows(t))
+        return out["vmax"].cpu().numpy(), out["prior"].cpu().numpy()
+    return evaluate
+
+
+class MCTSQ:
+    """Drop-in for the reference's MCTSQ (mcts_per.py:33-466): one environment, one tree."""
+
+    def __init__(self, env, seed: int, config: MCTSQConfiguration | None = None, log_path: str | None = None,
+                 tb_log: str | None = None, env_config: dict | None = None, device="cuda:0") -> None:
+        if config is not None:
+            self.__dict__.update(config.__dict__)
+        else:
+            with open("config/config_mctsq.yaml", "r", encoding="utf-8") as f:
+                self.__dict__.update(yaml.safe_load(f))
+        self.env, self.step, self.seed = env, None, seed
+        self.tb_log, self.log_path, self.writer = tb_log, log_path, None
+        if tb_log is not None:
+            try:                                        # tensorboard is optional here (mcts_per.py:66-67)
+                from torch.utils.tensorboard import SummaryWriter
+                self.writer = SummaryWriter(log_dir=tb_log)
+            except Exception as e:                      # noqa: BLE001
+                print(f"    > TensorBoard logging disabled: {e}")
+        if env_config is None:
+            with open("config/config_env.yaml", "r", encoding="utf-8") as f:
+                env_config = yaml.safe_load(f)
+        seq_len_price = env_config['price_ahead'] + env_config['price_past']          # :84
+        self.dqn = DQNModel(
+            el_input_dim=1, process_input_dim=6, gas_eua_input_dim=2, action_dim=env.action_space.n,
+            embed_dim=self.embed_dim, hidden_layers=self.hidden_layers, hidden_units=self.hidden_units,
+            buffer_capacity=self.buffer_size, batch_size=self.batch_size, gamma=self.discount_factor,
+            lr=self.learning_rate, price_encoder_type=self.price_encoder_type,
+            process_encoder_type=self.process_encoder_type, gas_eua_encoder_type=self.gas_eua_encoder_type,
+            activation=self.activation, learning_starts=self.learning_starts, seed=seed, device=device,
+            seq_lens=(seq_len_price, self.seq_length, 3))
+        self.dqn.policy_net.eval()                      # :114 (scripting at :115 has no meaning for the HIP path)
+        self.action_type, self.deterministic = "discrete", False
+        self.callback, self.callback_run = None, False
+        self.tree_remain, self.train_eval, self.treedepth = False, "train", 0
+        self._search = LockstepMCTS(1, _device_evaluator(self.dqn.policy_net), self.iterations, self.maximum_depth,
+                                    self.c_base, self.c_init, rngs=None)
+
+    @property
+    def root_node(self):
+        r = self._search.root[0]
+        return None if r < 0 else int(r)
+
+    def predict(self, state_c, train_eval: str = "train", deterministic: bool = False) -> int:
+        """mcts_per.py:220-258."""
+        self.deterministic, self.train_eval = deterministic, train_eval
+        env = self.callback.env if self.callback_run else self.env        # :330-335
+        train = train_eval == "train" and not self.callback_run
+        a = self._search.predict([state_c], lambda i, act, sc: env.step([act, sc]), train=train,
+                                 push=self.dqn.replay_buffer.push if train else None,
+                                 reuse=[self.tree_remain and train_eval == "train"])
+        self.tree_remain = True                                           # :247
+        self.treedepth = int(self._search.treedepth[0])
+        return int(a[0])
+
+    def learn(self, total_timesteps: int, callback) -> None:
+        """mcts_per.py:127-218: predict -> env step -> push -> update -> sub-tree reuse -> Polyak sync."""
+        state, info = self.env.reset()
+        state_c = info['state_c']
+        self.callback = callback
+        for self.step in range(total_timesteps):
+            action = self.predict(state_c, train_eval="train")
+            next_state, reward, terminated, _, info = self.env.step([action, state_c])
+            state_c = info['state_c']
+            self.dqn.replay_buffer.push(state, action, reward, next_state, terminated)
+            loss = self.dqn.update()
+            state = next_state
+            self._search.advance([action])                                # :153-167
+            if self.writer is not None and loss is not None:
+                self.writer.add_scalar("Training/Loss", float(loss), global_step=self.step)
+                self.writer.add_scalar("Training/TreeDepth", self.treedepth, global_step=self.step)
+            if terminated:
+                state, info = self.env.reset()
+                state_c = info['state_c']
+                self.tree_remain = False
+            if self.step % self.tree_remain_interval == 0 and self.step != 0:
+                self.tree_remain = False
+            self.dqn.update_target_network(self.tau)
+            if self.callback is not None and self.step % self.callback.val_steps == 0 and self.step != 0:
+                self.callback_run = True
+                _, info = self.callback.env.reset()
+                sc = info['state_c']
+                for _ in range(self.callback.env.eps_sim_steps):
+                    a = self.predict(sc, train_eval="eval")
+                    _, _, term, _, info = self.callback.env.step([a, sc])
+                    sc = info['state_c']
+                    if term:
+                        break
+                cum = info['cum_reward']
+                print(f"   >>Step: {self.step} - Cumulative Reward: {cum}")
+                if self.writer is not None:
+                    self.writer.add_scalar("Validation/CumulativeReward", cum, global_step=self.step)
+                self.callback_run = False
+                self.tree_remain = False
+                self._search.reset()                    # the validation search replaced the root (:245-247)
+        if self.writer is not None:
+            self.writer.close()
+
+    def save(self, filepath: str) -> None:
+        self.dqn.save(filepath)
+
+    def load(self, filepath: str) -> None:
+        self.dqn.load(filepath)
+
+    def test(self, env_config, eps_sim_steps_test: int):
+        """mcts_per.py:424-466: greedy roll-out on the test environment into the statistics dict."""
+        _, info = self.env.reset()
+        sc = info['state_c']
+        stats = np.zeros((eps_sim_steps_test, len(env_config.stats_names)))
+        codes = {'standby': 0, 'cooldown': 1, 'startup': 2, 'partial_load': 3}
+        for i in range(eps_sim_steps_test):
+            action = self.predict(sc, train_eval="eval")
+            _, _, terminated, _, info = self.env.step([action, sc])
+            sc = info['state_c']
+            if terminated:
+                break
+            for j, key in enumerate(info):
+                if j < 24:
+                    stats[i, j] = codes.get(info[key], 4) if key == 'Meth_Action' else info[key]
+        print(f"   >>Cumulative Reward {info['cum_reward']}")
+        return {name: stats[:eps_sim_steps_test, m] for m, name in enumerate(env_config.stats_names)}
+
+
+class LockstepAgent:
+    """K environments and K trees per process sharing ONE learner: every search iteration evaluates the K
+    new leaves in one launch; after each environment step the K root transitions and the transitions met
+    while expanding go to the replay buffer and the learner takes `updates_per_step` PER-DQN steps
+    (data-parallel over ranks when the DQNModel's learner has a process group)."""
+
+    def __init__(self, envs, dqn: DQNModel, iterations: int, maximum_depth: int, c_base: float, c_init: float,
+                 tau: float = 0.005, tree_remain_interval: int = 10, seed: int = 0, updates_per_step: int = 1):
+        self.envs, self.dqn, self.K = list(envs), dqn, len(envs)
+        self.tau, self.tree_remain_interval, self.updates_per_step = tau, tree_remain_interval, updates_per_step
+        self.search = LockstepMCTS(self.K, _device_evaluator(dqn.policy_net), iterations, maximum_depth, c_base,
+                                   c_init, rngs=[random.Random(seed * 1000003 + i) for i in range(self.K)])
+        res = [e.reset() for e in self.envs]
+        self.obs = [r[0] for r in res]
+        self.state_c = [r[1]['state_c'] for r in res]
+        self.keep = np.zeros(self.K, dtype=bool)
+        self.step_count, self.leaf_evals = 0, 0
+
+    def step(self, train: bool = True):
+        """One environment step of every tree; returns (actions, rewards, loss of the last update)."""
+        K, envs = self.K, self.envs
+        push = self.dqn.replay_buffer.push if train else None
+        n0 = self.search.n
+        actions = self.search.predict(self.state_c, lambda i, a, sc: envs[i].step([a, sc]), train=train, push=push,
+                                      reuse=self.keep)
+        self.leaf_evals += K * self.search.iterations + (n0 if train else 0) + K
+        rewards = np.zeros(K)
+        term = np.zeros(K, dtype=bool)
+        for i in range(K):
+            nobs, rewards[i], term[i], _, info = envs[i].step([int(actions[i]), self.state_c[i]])
+            if train:
+                self.dqn.replay_buffer.push(self.obs[i], int(actions[i]), rewards[i], nobs, bool(term[i]))
+            self.obs[i], self.state_c[i] = nobs, info['state_c']
+            if term[i]:
+                self.obs[i], info = envs[i].reset()
+                self.state_c[i] = info['state_c']
+        loss = None
+        if train:
+            for _ in range(self.updates_per_step):
+                loss = self.dqn.update()
+                self.dqn.update_target_network(self.tau)
+        self.step_count += 1
+        self.keep[:] = True
+        self.keep[term] = False
+        if self.step_count % self.tree_remain_interval == 0:
+            self.keep[:] = False
+        self.search.advance(actions, keep=self.keep)
+        return actions, rewards, loss

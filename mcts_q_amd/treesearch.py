@@ -1,0 +1,281 @@
+"""Lock-step MCTS over K independent trees: the host-side caller that turns the reference's per-node
+B = 1 network calls into one coalesced leaf batch per search iteration.
+
+Restates, tree for tree, the search of MCTSQ.predict / _select / _expand / _evaluate / _backpropagate and
+MCTSNode (/root/reference/src/mctsq_config_mcts_per.py:220-381, 468-553): PUCT selection with the
+exploration constant C(s) = log((1 + N + c_base) / c_base) + c_init, random choice among the untried legal
+actions, value = max_a Q(leaf), prior = softmax(Q(child))[child.action], visit / value backup to the root,
+most-visited child as the result, legal actions by `Meth_State`, sub-tree reuse between environment steps.
+The serial tree logic stays on the host (vectorised over trees with numpy); the only device work is the
+leaf batch.
+
+Two facts make one launch per iteration enough without changing any result:
+  * the network weights do not change inside predict(), so the quantities the reference recomputes on
+    every visit (the prior of a child, the value of a terminal node it lands on again) are constants of
+    the node: they are taken from the single evaluation the node gets when it is created;
+  * a retained sub-tree is re-evaluated in one batch when predict() starts (the weights moved since).
+
+All tree arithmetic is float64 in the reference's operation order, so with the same Q values the chosen
+actions and visit counts are identical to K sequential reference searches (tests/test_treesearch_*.py
+check this against oracle/mcts_ref.py).  Children are kept in creation order: `max(children, key=...)`
+returns the first maximum in that order (mcts_per.py:308, 553).
+"""
+from __future__ import annotations
+
+import math
+import random
+
+import numpy as np
+
+from .leafbatch import ROW, obs_to_row
+
+N_ACT = 5
+# MCTSNode.get_legal_actions (mcts_per.py:524-546) as bit masks over actions 0..4
+_LEGAL = {0: 0b00111, 1: 0b00111, 2: 0b11011, 3: 0b11011, 4: 0b11011}
+_ALL = 0b11111
+_ACTIONS_OF = [[a for a in range(N_ACT) if m >> a & 1] for m in range(32)]
+
+
+def legal_mask(meth_state) -> int:
+    try:
+        return _LEGAL.get(int(meth_state), _ALL)
+    except (TypeError, ValueError):
+        return _ALL
+
+
+class LockstepMCTS:
+    """K trees advanced together.
+
+    evaluate(rows) -> (vmax, prior): rows fp32 [n, 91] (leafbatch.obs_to_row layout) -> fp32 [n] max_a Q and
+    fp32 [n, A] softmax(Q); ONE device launch per call (DeviceQNet.forward).
+    env_step(i, action, state_c) -> (next_obs, reward, terminated, truncated, info): the `_per` environment
+    protocol, a pure function of (action, state_c) with info['state_c'] the successor (ptg_gym_env_per.py:422-431).
+    push(state, action, reward, next_state, terminated): replay sink for transitions met while expanding in
+    training mode (mcts_per.py:336-340), or None.
+    """
+
+    def __init__(self, n_trees: int, evaluate, iterations: int, maximum_depth: int, c_base: float, c_init: float,
+                 rngs=None):
+        self.K = int(n_trees)
+        self.evaluate = evaluate
+        self.iterations = int(iterations)
+        self.maximum_depth = int(maximum_depth)
+        self.c_base, self.c_init = c_base, c_init
+        # one random stream per tree; None = the global `random` module, as the reference uses (:328)
+        self.rngs = list(rngs) if rngs is not None else [random] * self.K
+        assert len(self.rngs) == self.K
+        self.root = np.full(self.K, -1, dtype=np.int64)
+        self.treedepth = np.zeros(self.K, dtype=np.int64)
+        self._alloc(0)
+        self.n = 0
+        self._logtab = []
+
+    # ---- storage ------------------------------------------------------------------------------
+    def _alloc(self, cap):
+        self.cap = cap
+        self.parent = np.full(cap, -1, dtype=np.int64)
+        self.action = np.full(cap, -1, dtype=np.int64)
+        self.visits = np.zeros(cap, dtype=np.int64)
+        self.total = np.zeros(cap, dtype=np.float64)
+        self.depth = np.zeros(cap, dtype=np.int64)
+        self.done = np.zeros(cap, dtype=bool)
+        self.legal = np.zeros(cap, dtype=np.int64)
+        self.tried = np.zeros(cap, dtype=np.int64)
+        self.nchild = np.zeros(cap, dtype=np.int64)
+        self.child = np.full((cap, N_ACT), -1, dtype=np.int64)      # creation order
+        self.vmax = np.zeros(cap, dtype=np.float64)
+        self.prior_a = np.zeros(cap, dtype=np.float64)
+        self.rows = np.zeros((cap, ROW), dtype=np.float32)
+        self.state_c = [None] * cap
+        self.extra = [None] * cap           # (meth_state_tr, el_price_tr, pot_reward_tr) of mcts_per.py:351-353
+
+    def _grow(self, need):
+        if need <= self.cap:
+            return
+        old = self.__dict__.copy()
+        cap = max(need, 2 * self.cap, 1024)
+        self._alloc(cap)
+        n = old["n"] if "n" in old else 0
+        for k in ("parent", "action", "visits", "total", "depth", "done", "legal", "tried", "nchild", "child",
+                  "vmax", "prior_a", "rows"):
+            getattr(self, k)[:n] = old[k][:n]
+        self.state_c[:n] = old["state_c"][:n]
+        self.extra[:n] = old["extra"][:n]
+
+    def _new_nodes(self, state_cs, parents, actions, dones, depths, extras=None):
+        """Append nodes (MCTSNode.__init__, :472-506); returns their ids."""
+        m = len(state_cs)
+        self._grow(self.n + m)
+        ids = np.arange(self.n, self.n + m)
+        self.n += m
+        self.parent[ids], self.action[ids] = parents, actions
+        self.visits[ids], self.total[ids] = 0, 0.0
+        self.depth[ids], self.done[ids] = depths, dones
+        self.tried[ids], self.nchild[ids] = 0, 0
+        self.child[ids] = -1
+        for j, i in enumerate(ids):
+            sc = state_cs[j]
+            self.state_c[i] = sc
+            self.extra[i] = extras[j] if extras is not None else None
+            self.legal[i] = legal_mask(sc['Meth_State'])
+            self.rows[i] = obs_to_row(sc['obs_norm'])
+        return ids
+
+    def _c_puct(self, tv):
+        """math.log((1 + N + c_base) / c_base) + c_init per total visit count (:273), tabulated."""
+        top = int(tv.max()) if len(tv) else 0
+        while len(self._logtab) <= top:
+            n = len(self._logtab)
+            self._logtab.append(math.log((1 + n + self.c_base) / self.c_base) + self.c_init)
+        return np.asarray(self._logtab, dtype=np.float64)[tv]
+
+    def _evaluate_nodes(self, ids):
+        if len(ids) == 0:
+            return
+        vmax, prior = self.evaluate(self.rows[ids])
+        self.vmax[ids] = np.asarray(vmax, dtype=np.float32).astype(np.float64)          # q.max().item() (:370)
+        prior = np.asarray(prior, dtype=np.float32)
+        act = np.where(self.action[ids] >= 0, self.action[ids], 0)
+        self.prior_a[ids] = prior[np.arange(len(ids)), act].astype(np.float64)          # prior[idx, action].item() (:296)
+
+    # ---- sub-tree reuse (mcts_per.py:153-167, 236-247) -----------------------------------------
+    def _retain(self, keep_roots):
+        """Compact the arrays to the sub-trees under keep_roots[i] (>= 0), re-rooted at depth 0."""
+        K = self.K
+        if self.n == 0 or not (keep_roots >= 0).any():
+            self.n = 0
+            return np.full(K, -1, dtype=np.int64)
+        mark = np.zeros(self.n, dtype=bool)
+        rel = np.zeros(self.n, dtype=np.int64)
+        frontier = keep_roots[keep_roots >= 0]
+        mark[frontier] = True
+        d = 0
+        while len(frontier):
+            rel[frontier] = d
+            ch = self.child[frontier].ravel()
+            frontier = ch[ch >= 0]
+            mark[frontier] = True
+            d += 1
+        old_ids = np.nonzero(mark)[0]
+        remap = np.full(self.n + 1, -1, dtype=np.int64)           # remap[-1] stays -1
+        remap[old_ids] = np.arange(len(old_ids))
+        for k in ("action", "visits", "total", "done", "legal", "tried", "nchild", "vmax", "prior_a", "rows"):
+            arr = getattr(self, k)
+            arr[:len(old_ids)] = arr[old_ids]
+        self.depth[:len(old_ids)] = rel[old_ids]                 # reset_depths (:239-243)
+        self.parent[:len(old_ids)] = remap[self.parent[old_ids]]
+        self.child[:len(old_ids)] = remap[self.child[old_ids]]
+        self.state_c[:len(old_ids)] = [self.state_c[i] for i in old_ids]
+        self.extra[:len(old_ids)] = [self.extra[i] for i in old_ids]
+        self.n = len(old_ids)
+        new_roots = np.where(keep_roots >= 0, remap[keep_roots], -1)
+        self.parent[new_roots[new_roots >= 0]] = -1               # detach from the previous root (:162)
+        return new_roots
+
+    def advance(self, actions, keep=None):
+        """After the environment took `actions`: the matching child becomes the next root (:154-165);
+        trees with keep[i] False (episode end, tree_remain interval, validation) start fresh."""
+        nxt = np.full(self.K, -1, dtype=np.int64)
+        for i in range(self.K):
+            r = self.root[i]
+            if r < 0 or (keep is not None and not keep[i]):
+                continue
+            for s in range(self.nchild[r]):
+                c = self.child[r, s]
+                if self.action[c] == actions[i]:
+                    nxt[i] = c
+                    break
+        self.root = self._retain(nxt)
+
+    def reset(self, mask=None):
+        """Forget the trees with mask[i] True (all if None)."""
+        keep = self.root.copy()
+        if mask is None:
+            keep[:] = -1
+        else:
+            keep[np.asarray(mask, dtype=bool)] = -1
+        self.root = self._retain(keep)
+
+    # ---- the search ---------------------------------------------------------------------------
+    def predict(self, state_cs, env_step, train: bool = True, push=None, reuse=None):
+        """One MCTS search per tree from state_cs[i]; returns the most-visited root action of every tree
+        (int64 [K]).  reuse[i] True keeps tree i's retained sub-tree (if advance() left one)."""
+        K = self.K
+        assert len(state_cs) == K
+        self.treedepth[:] = 0
+        keep = self.root.copy()
+        if reuse is None or not train:                 # a retained tree is only used in training mode (:236)
+            keep[:] = -1
+        else:
+            keep[~np.asarray(reuse, dtype=bool)] = -1
+        self.root = self._retain(keep)
+        fresh = np.nonzero(self.root < 0)[0]
+        if len(fresh):
+            ids = self._new_nodes([state_cs[i] for i in fresh], -1, -1, False, 0)
+            self.root[fresh] = ids
+        self._evaluate_nodes(np.arange(self.n))        # fresh roots + retained sub-trees under the current weights
+        trees = np.arange(K)
+        maxd = self.maximum_depth
+        for _ in range(self.iterations):
+            # -- selection (:266-308), all trees level by level
+            cur = self.root.copy()
+            while True:
+                terminal = self.done[cur] | (self.depth[cur] >= maxd)
+                go = ~terminal & (self.tried[cur] == self.legal[cur])
+                if not go.any():
+                    break
+                t = trees[go]
+                node = cur[t]
+                ch = self.child[node]                                     # [n, 5] creation order
+                valid = ch >= 0
+                chs = np.where(valid, ch, 0)
+                v = np.where(valid, self.visits[chs], 0)
+                tv = v.sum(1)
+                c_puct = self._c_puct(tv)
+                vf = v.astype(np.float64)
+                mean = np.where(v > 0, self.total[chs] / np.where(v > 0, vf, 1.0), 0.0)
+                explore = c_puct[:, None] * self.prior_a[chs] * np.sqrt(tv.astype(np.float64))[:, None] / (1 + vf)
+                score = np.where(valid, mean + explore, -np.inf)
+                cur[t] = ch[np.arange(len(t)), np.argmax(score, axis=1)]
+            # -- expansion (:312-356)
+            terminal = self.done[cur] | (self.depth[cur] >= maxd)
+            exp = trees[~terminal]
+            if len(exp):
+                scs, acts, dones, extras = [], [], [], []
+                for i in exp:
+                    node = cur[i]
+                    untried = _ACTIONS_OF[self.legal[node] & ~self.tried[node] & _ALL]
+                    a = self.rngs[i].choice(untried)
+                    next_obs, reward, terminated, truncated, info = env_step(i, a, self.state_c[node])
+                    sc = info['state_c']
+                    if train and push is not None:
+                        # the reference pushes state == next state's observation here (:337-340)
+                        push(sc['obs_norm'], a, reward, next_obs, terminated)
+                    scs.append(sc); acts.append(a); dones.append(bool(terminated or truncated))
+                    extras.append((info.get('Meth_State'), info.get('el_price_act'), info.get('Pot_Reward')))
+                par = cur[exp]
+                ids = self._new_nodes(scs, par, np.asarray(acts), np.asarray(dones), self.depth[par] + 1, extras)
+                par = cur[exp]                                            # (arrays may have been regrown)
+                self.child[par, self.nchild[par]] = ids
+                self.nchild[par] += 1
+                self.tried[par] |= 1 << np.asarray(acts)
+                self.treedepth[exp] = np.maximum(self.treedepth[exp], self.depth[ids])
+                cur[exp] = ids
+                self._evaluate_nodes(ids)                                  # ONE launch: the iteration's leaves
+            # -- evaluation + backup (:358-381)
+            value = self.vmax[cur]
+            node = cur.copy()
+            live = node >= 0
+            while live.any():
+                nl = node[live]
+                self.visits[nl] += 1
+                self.total[nl] += value[live]
+                node[live] = self.parent[nl]
+                live = node >= 0
+        # -- most visited child, first maximum in creation order (:256, 553)
+        if (self.nchild[self.root] == 0).any():
+            raise ValueError("most_visited_child of a root without children (terminal root or iterations == 0)")
+        ch = self.child[self.root]
+        v = np.where(ch >= 0, self.visits[np.where(ch >= 0, ch, 0)], -1)
+        best = ch[trees, np.argmax(v, axis=1)]
+        return self.action[best]

@@ -1,0 +1,105 @@
+"""Lock-step tree driver with the HIP network behind it (mcts_q_amd/treesearch.py, mcts.py) against the
+per-node reference search of oracle/mcts_ref.py running the torch-CPU oracle network with the same weights.
+Q differs between the two by fp32 rounding (~1e-7), which can flip a PUCT near-tie, so the bar is: root
+visit distributions identical on (nearly) every tree, never a different most-visited action where the
+reference's top two visit counts differ by more than one."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from mcts_q_amd import NetSpec
+from mcts_q_amd.synthetic_env import FakeGymEnv, FakePerEnv
+from oracle import mcts_ref, torch_ref
+
+pytestmark = pytest.mark.gpu
+CFG = dict(price="gru", process="gru", gas="gru", act="relu", flavor="per")
+MCFG = dict(iterations=30, c_init=1.25, c_base=19652, maximum_depth=42, learning_rate=1e-3, discount_factor=0.99,
+            buffer_size=5000, batch_size=32, hidden_layers=2, hidden_units=128, activation='relu', tau=0.005,
+            seq_length=10, embed_dim=64, price_encoder_type='gru', process_encoder_type='gru',
+            gas_eua_encoder_type='gru', learning_starts=40, tree_remain_interval=5, seq_step=30)
+ENVCFG = dict(price_ahead=13, price_past=12, time_step_op=2)
+
+
+def test_lockstep_hip_search_matches_reference_search():
+    from mcts_q_amd.leafbatch import split_rows
+    from mcts_q_amd.qnet import DeviceQNet
+    from mcts_q_amd.treesearch import LockstepMCTS
+    torch.manual_seed(0)
+    ref_net = torch_ref.RefQNet(CFG).eval()
+    sd = {k: v.detach().numpy() for k, v in ref_net.state_dict().items()}
+    net = DeviceQNet(NetSpec.from_cfg(CFG)).load_state_dict(sd)
+    launches = [0]
+
+    def evaluate(rows):
+        launches[0] += 1
+        out = net(*split_rows(torch.from_numpy(np.ascontiguousarray(rows)).cuda()))
+        return out["vmax"].cpu().numpy(), out["prior"].cpu().numpy()
+
+    def q_fn(p, q, g):
+        with torch.no_grad():
+            return ref_net(p, q, g)
+
+    K, iters = 48, 30
+    envs = [FakePerEnv(seed=i) for i in range(K)]
+    drv = LockstepMCTS(K, evaluate, iters, 42, 19652, 1.25, rngs=[random.Random(7 + i) for i in range(K)])
+    scs = [e.reset()[1]["state_c"] for e in envs]
+    acts = drv.predict(scs, lambda i, a, sc: envs[i].step([a, sc]), train=False)
+    assert launches[0] == iters + 1                      # one leaf batch per iteration (+ the roots)
+    same, bad = 0, 0
+    for i in range(K):
+        ref = mcts_ref.RefSearch(q_fn, envs[i], iters, 42, 19652, 1.25, random.Random(7 + i))
+        a_ref = ref.predict(scs[i], "eval")
+        root = drv.root[i]
+        got = [(int(drv.action[c]), int(drv.visits[c])) for c in drv.child[root][:drv.nchild[root]]]
+        exp = [(c.action, c.visits) for c in ref.root.children]
+        same += got == exp
+        v = sorted((c.visits for c in ref.root.children), reverse=True)
+        if acts[i] != a_ref and (len(v) < 2 or v[0] - v[1] > 1):
+            bad += 1
+    print(f"identical root visit distributions: {same}/{K}")
+    assert same >= int(0.9 * K) and bad == 0
+
+
+def test_mctsq_learn_predict_save_load(tmp_path):
+    from mcts_q_amd.mcts import MCTSQ, MCTSQConfiguration
+
+    class Cb:
+        env, val_steps = FakeGymEnv(99, eps_sim_steps=3), 25
+
+    agent = MCTSQ(FakeGymEnv(1, horizon=20), seed=3, config=MCTSQConfiguration(values=dict(MCFG)), env_config=ENVCFG)
+    agent.learn(40, Cb())
+    n = len(agent.dqn.replay_buffer)
+    assert n >= 40                                      # 1 + #expansions pushes per step (mcts_per.py:148, 340)
+    loss = agent.dqn.update()
+    assert loss is not None and np.isfinite(float(loss))
+    path = os.path.join(tmp_path, "ckpt.pt")
+    agent.save(path)
+    other = MCTSQ(FakeGymEnv(1), seed=4, config=MCTSQConfiguration(values=dict(MCFG)), env_config=ENVCFG)
+    other.load(path)
+    sc = FakeGymEnv(5).reset()[1]["state_c"]
+    random.seed(11); a1 = agent.predict(sc, "eval")
+    random.seed(11); a2 = other.predict(sc, "eval")
+    assert a1 == a2 and 0 <= a1 < 5
+
+
+def test_lockstep_agent_many_trees_one_learner():
+    from mcts_q_amd.dqn import DQNModel
+    from mcts_q_amd.mcts import LockstepAgent
+    dqn = DQNModel(1, 6, 2, 5, 64, 2, 128, buffer_capacity=20000, batch_size=64, gamma=0.99, lr=1e-3,
+                   price_encoder_type="gru", process_encoder_type="gru", gas_eua_encoder_type="gru",
+                   learning_starts=64, seed=1)
+    K = 32
+    agent = LockstepAgent([FakePerEnv(i, horizon=6) for i in range(K)], dqn, iterations=10, maximum_depth=42,
+                          c_base=19652, c_init=1.25, tree_remain_interval=3)
+    losses = []
+    for _ in range(8):
+        acts, rew, loss = agent.step()
+        assert acts.shape == (K,) and ((0 <= acts) & (acts < 5)).all()
+        if loss is not None:
+            losses.append(float(loss))
+    # root transition + at most one expansion per iteration and tree (terminal leaves are not expanded)
+    assert 8 * K < len(dqn.replay_buffer) <= 8 * K * (1 + 10)
+    assert losses and np.isfinite(losses).all()

@@ -1,0 +1,110 @@
+"""Host logic of the lock-step tree driver (mcts_q_amd/treesearch.py) against the per-node restatement of
+the reference's search (oracle/mcts_ref.py), with the SAME CPU network on both sides so that the comparison
+isolates the tree logic: chosen actions, visit counts, values and replay pushes must be identical."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from mcts_q_amd.leafbatch import split_rows
+from mcts_q_amd.treesearch import LockstepMCTS, legal_mask
+from oracle import mcts_ref, torch_ref
+from mcts_q_amd.synthetic_env import FakePerEnv
+
+CFG = dict(price="gru", process="gru", gas="gru", act="relu", flavor="per")
+
+
+def _net(seed=0):
+    torch.manual_seed(seed)
+    return torch_ref.RefQNet(CFG).eval()
+
+
+def _rowwise(net):
+    """torch's CPU kernels are not batch-invariant (blocking changes the fp32 rounding), and the two sides
+    batch differently by design; evaluating one row at a time on both sides isolates the tree logic."""
+    def q_fn(price, process, gas):
+        with torch.no_grad():
+            return torch.cat([net(price[i:i + 1], process[i:i + 1], gas[i:i + 1]) for i in range(price.shape[0])])
+    return q_fn
+
+
+def _evaluator(net):
+    q_fn = _rowwise(net)
+
+    def ev(rows):
+        q = q_fn(*split_rows(torch.from_numpy(np.ascontiguousarray(rows))))
+        return q.max(1)[0].numpy(), torch.softmax(q, -1).numpy()
+    return ev
+
+
+def test_legal_masks():
+    assert legal_mask(0) == legal_mask(1) == 0b00111
+    assert legal_mask(2) == legal_mask(3) == legal_mask(4) == 0b11011
+    assert legal_mask(7) == legal_mask("x") == 0b11111
+
+
+@pytest.mark.parametrize("K,iters,maxd,horizon", [(1, 50, 42, 1000), (5, 30, 3, 1000), (4, 40, 42, 2)])
+def test_lockstep_equals_sequential_reference_search(K, iters, maxd, horizon):
+    net = _net()
+    envs = [FakePerEnv(seed=i, horizon=horizon) for i in range(K)]
+    drv_push, ref_push = [[] for _ in range(K)], [[] for _ in range(K)]
+    drv = LockstepMCTS(K, _evaluator(net), iters, maxd, c_base=19652, c_init=1.25,
+                       rngs=[random.Random(100 + i) for i in range(K)])
+    refs = [mcts_ref.RefSearch(_rowwise(net), envs[i], iters, maxd, 19652, 1.25, random.Random(100 + i),
+                               push=lambda *a, i=i: ref_push[i].append(a)) for i in range(K)]
+    scs = [e.reset()[1]["state_c"] for e in envs]
+    ref_scs = list(scs)
+    for step in range(4):                                           # four env steps with sub-tree reuse
+        cur_i = [None]
+
+        def env_step(i, a, sc):
+            cur_i[0] = i
+            return envs[i].step([a, sc])
+
+        def push(*a):
+            drv_push[cur_i[0]].append(a)
+
+        acts = drv.predict(scs, env_step, train=True, push=push, reuse=[True] * K)
+        for i in range(K):
+            a_ref = refs[i].predict(ref_scs[i], "train")
+            assert acts[i] == a_ref, (step, i)
+            root, rr = drv.root[i], refs[i].root
+            assert drv.visits[root] == rr.visits and drv.total[root] == rr.total_value
+            got = [(drv.action[c], drv.visits[c], drv.total[c]) for c in drv.child[root][:drv.nchild[root]]]
+            exp = [(c.action, c.visits, c.total_value) for c in rr.children]
+            assert got == exp
+            assert drv.treedepth[i] == refs[i].treedepth
+            assert len(drv_push[i]) == len(ref_push[i])
+            for x, y in zip(drv_push[i], ref_push[i]):
+                assert x[1] == y[1] and x[2] == y[2] and x[4] == y[4]
+                assert all(np.array_equal(x[0][k], y[0][k]) and np.array_equal(x[3][k], y[3][k]) for k in x[0])
+        res = [envs[i].step([int(acts[i]), scs[i]]) for i in range(K)]
+        term = np.array([r[2] for r in res])
+        # learn(): an episode end resets the environment and drops the tree (mcts_per.py:173-176)
+        nxt = [envs[i].reset()[1]["state_c"] if term[i] else res[i][4]["state_c"] for i in range(K)]
+        scs, ref_scs = nxt, list(nxt)
+        drv.advance(acts, keep=~term)
+        for i in range(K):
+            refs[i].advance(int(acts[i]))
+            if term[i]:
+                refs[i].tree_remain = False
+
+
+def test_eval_mode_starts_fresh_and_does_not_push():
+    net = _net(1)
+    env = FakePerEnv(3)
+    drv = LockstepMCTS(1, _evaluator(net), 20, 42, 19652, 1.25, rngs=[random.Random(5)])
+    sc = env.reset()[1]["state_c"]
+    pushed = []
+    a = drv.predict([sc], lambda i, a, s: env.step([a, s]), train=False, push=lambda *x: pushed.append(x))
+    assert pushed == [] and 0 <= a[0] < 5
+    assert drv.visits[drv.root[0]] == 20
+
+
+def test_terminal_root_raises_like_reference():
+    net = _net(1)
+    env = FakePerEnv(3)
+    drv = LockstepMCTS(1, _evaluator(net), 5, 0, 19652, 1.25, rngs=[random.Random(5)])
+    with pytest.raises(ValueError):
+        drv.predict([env.reset()[1]["state_c"]], lambda i, a, s: env.step([a, s]))
