@@ -148,9 +148,9 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     if (save)
         for (int i = 0; i + 1 < L.n_fc; ++i) ha.sv_act[i] = sv_act[i];
 
-    if (!save && fused_gru_head_applicable(ga, ha)) {        // shipped default: one launch
-        ga.feats = nullptr;
-        if (launch_gru3_head_fwd(ga, ha, false, st)) return -1;
+    if (fused_gru_head_applicable(ga, ha)) {                 // shipped default: one launch
+        if (!save) ga.feats = nullptr;                       // training keeps the feature rows for the head backward
+        if (launch_gru3_head_fwd(ga, ha, save, st)) return -1;
         if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
         return 0;
     }

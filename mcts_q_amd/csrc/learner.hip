@@ -185,12 +185,21 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         const float v = row16_sum(dpool[r] * pooled[r]);
         if (jl == 0) L.red[2][wq][4 * q + r] = v;
     }
-    for (int t = 0; t < S; ++t) {
+    for (int t0 = 0; t0 < S; t0 += 8) {                       // 32 loads in flight per lane, then the sums
+        float hv[8][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float h = s.sv_h[((int64_t)(t + 1) * Bp + row0 + 4 * q + r) * E + j];
-            const float v = row16_sum(dpool[r] * h);
-            if (jl == 0) (&L.pe[t][4 * q + r].x)[wq] = v;
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                hv[u][r] = t0 + u < S ? s.sv_h[((int64_t)(t0 + u + 1) * Bp + row0 + 4 * q + r) * E + j] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (t0 + u >= S) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = row16_sum(dpool[r] * hv[u][r]);
+                if (jl == 0) (&L.pe[t0 + u][4 * q + r].x)[wq] = v;
+            }
         }
     }
     __syncthreads();
@@ -272,11 +281,17 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
 }
 
 // ====================================================================== weight-gradient GEMM
-// Block = 4 waves = a 64 x 64 output tile of one (job, K split); wave w owns rows 16w..16w+15.
-// A operand lane (m = l&15, k = l>>4) reads A[k0+k][m]; B operand lane (n = l&15, k = l>>4) reads
-// Bm[k0+k][n]: both are 4 rows x 64 contiguous bytes per wave instruction.
+// dW[m][n] = sum_k A[k][m] * Bm[k][n] over a K chunk: block = 4 waves = a 64 x 64 output tile of one
+// (job, K split); wave w owns rows 16w..16w+15 of the tile and all four 16-column tiles.
+// The chunk is walked in slabs of 32 k-rows staged through LDS: every lane fetches 8 + 8 dwords (each
+// wave instruction = one contiguous 256-byte row segment), the next slab's fetch is in flight while the
+// current one feeds the MFMAs (double-buffered LDS, one barrier per slab).  Operand reads from LDS are
+// conflict-free with the row stride 80 (4 k-rows land in 4 disjoint groups of 16 banks).  Column sums of
+// A (bias gradients) ride along as VALU adds.
+constexpr int WG_KT = 32, WG_LD = 80;
 __global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, const float* __restrict__ ws,
                                                     float* __restrict__ partials) {
+    __shared__ float As[2][WG_KT * WG_LD], Bs[2][WG_KT * WG_LD];
     int ji = 0;
     for (int k = 1; k < jl.njobs; ++k)
         if ((int)blockIdx.x >= jl.job[k].blk0) ji = k;
@@ -284,53 +299,82 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, const float* __
     if (J.a_off < 0) return;                                  // partials written by another kernel
     const int lb = blockIdx.x - J.blk0, per = J.mblocks * J.nblocks;
     const int split = lb / per, rem = lb - split * per, mb = rem / J.nblocks, nb = rem - mb * J.nblocks;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jl_ = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl_ = lane & 15, q = lane >> 4;
     const int M = J.M, N = J.N;
-    const int m0 = mb * 64 + 16 * w, n0 = nb * 64;
-    if (m0 >= M) return;
-    const int64_t k0 = (int64_t)split * J.kchunk;
-    const int64_t k1 = k0 + J.kchunk < J.K ? k0 + J.kchunk : J.K;
-    const bool m_ok = m0 + jl_ < M;
+    const int mbase = mb * 64, n0 = nb * 64, m0 = mbase + 16 * w;
+    const int k0 = split * J.kchunk;
+    const int k1 = k0 + J.kchunk < J.K ? k0 + J.kchunk : J.K;
     const bool do_bias = nb == 0;
     const bool has_b = J.b_off >= 0;
     const int ntile = has_b ? min(4, (N - n0 + 15) >> 4) : 0;
-    const float* ap = ws + J.a_off + (k0 + q) * J.lda + m0 + jl_;
-    const float* bp = has_b ? ws + J.b_off + (k0 + q) * J.ldb + n0 + jl_ : nullptr;
-    bool n_ok[4];
+    const bool wave_live = m0 < M;                            // wave-uniform
+    // staging role of this lane: column c of rows r, r+4, ... of the slab
+    const int c = tid & 63, r = tid >> 6;
+    const bool a_ok = mbase + c < M, b_ok = has_b && n0 + c < N;
+    const float* ag = ws + J.a_off + (int64_t)(k0 + r) * J.lda + mbase + c;
+    const float* bg = has_b ? ws + J.b_off + (int64_t)(k0 + r) * J.ldb + n0 + c : nullptr;
+    const int64_t astep = 4 * (int64_t)J.lda, bstep = 4 * (int64_t)J.ldb;
+    float ra[8], rb[8];
+    auto fetch = [&](int kb) {                                // slab starting at k-row kb -> registers
 #pragma unroll
-    for (int t = 0; t < 4; ++t) n_ok[t] = t < ntile && n0 + 16 * t + jl_ < N;
+        for (int p = 0; p < 8; ++p) {
+            const bool kin = kb + r + 4 * p < k1;
+            ra[p] = (a_ok && kin) ? ag[p * astep] : 0.0f;
+            rb[p] = (b_ok && kin) ? bg[p * bstep] : 0.0f;
+        }
+        ag += 8 * astep;
+        if (has_b) bg += 8 * bstep;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            As[buf][(r + 4 * p) * WG_LD + c] = ra[p];
+            Bs[buf][(r + 4 * p) * WG_LD + c] = rb[p];
+        }
+    };
     f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    f32x4 accb = {0, 0, 0, 0};
-    const int64_t astep = 4 * (int64_t)J.lda, bstep = has_b ? 4 * (int64_t)J.ldb : 0;
-#pragma unroll 8
-    for (int64_t k = k0; k < k1; k += 4) {
-        const float av = m_ok ? *ap : 0.0f;
-        ap += astep;
-        if (ntile > 0) acc[0] = mfma16(av, n_ok[0] ? bp[0] : 0.0f, acc[0]);
-        if (ntile > 1) acc[1] = mfma16(av, n_ok[1] ? bp[16] : 0.0f, acc[1]);
-        if (ntile > 2) acc[2] = mfma16(av, n_ok[2] ? bp[32] : 0.0f, acc[2]);
-        if (ntile > 3) acc[3] = mfma16(av, n_ok[3] ? bp[48] : 0.0f, acc[3]);
-        if (do_bias) accb = mfma16(av, 1.0f, accb);
-        bp += bstep;
+    float bsum = 0.0f;
+    fetch(k0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = k0; kb < k1; kb += WG_KT) {
+        const bool more = kb + WG_KT < k1;
+        if (more) fetch(kb + WG_KT);
+        if (wave_live) {
+            const float* ap = &As[buf][q * WG_LD + 16 * w + jl_];
+            const float* bp = &Bs[buf][q * WG_LD + jl_];
+#pragma unroll
+            for (int ks = 0; ks < WG_KT / 4; ++ks) {
+                const float av = ap[ks * 4 * WG_LD];
+                if (ntile > 0) acc[0] = mfma16(av, bp[ks * 4 * WG_LD], acc[0]);
+                if (ntile > 1) acc[1] = mfma16(av, bp[ks * 4 * WG_LD + 16], acc[1]);
+                if (ntile > 2) acc[2] = mfma16(av, bp[ks * 4 * WG_LD + 32], acc[2]);
+                if (ntile > 3) acc[3] = mfma16(av, bp[ks * 4 * WG_LD + 48], acc[3]);
+                bsum += av;
+            }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
+    if (!wave_live) return;
     float* P = partials + J.part_off + (int64_t)split * ((int64_t)M * N + M);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t < ntile) {
             const int n = n0 + 16 * t + jl_;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 4 * q + r;
-                if (m < M && n < N) P[(int64_t)m * N + n] = acc[t][r];
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + 4 * q + rr;
+                if (m < M && n < N) P[(int64_t)m * N + n] = acc[t][rr];
             }
         }
     }
-    if (do_bias && jl_ == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * q + r;
-            if (m < M) P[(int64_t)M * N + m] = accb[r];
-        }
+    if (do_bias) {                                            // column sums of A: fold the four k groups
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (q == 0 && m0 + jl_ < M) P[(int64_t)M * N + m0 + jl_] = bsum;
     }
 }
 
@@ -349,7 +393,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const fl
     const int64_t le = e - base, mn = (int64_t)J.M * J.N, stride = mn + J.M;
     const float* p = partials + J.part_off + le;
     float acc = 0.0f;
-    for (int sp = 0; sp < J.nsplit; ++sp) acc += p[(int64_t)sp * stride];
+    int sp = 0;
+    for (; sp + 8 <= J.nsplit; sp += 8) {                     // eight loads in flight, summed in split order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sp < J.nsplit; ++sp) acc += p[(int64_t)sp * stride];
     if (le < mn) {
         if (J.out_w >= 0) {
             const int64_t m = le / J.N, n = le - m * J.N;

@@ -1,8 +1,11 @@
 // mctsq_dqn_grad: the learner step of DQNModel.update (dqn_per.py:455-470) on an already gathered
 // batch.  Host side: carve the caller's workspace, enqueue target forward -> policy forward (keeping
 // activations) -> TD loss -> head backward -> encoder backward -> weight-gradient GEMMs -> ordered
-// reduction into the flat gradient buffer.  Everything runs on the caller's stream.
+// reduction into the flat gradient buffer.  The target forward runs on a helper stream forked from and
+// joined to the caller's stream with events; everything else is enqueued on the caller's stream.
 #include <string.h>
+
+#include <mutex>
 
 #include "forward.hpp"
 #include "learner.hpp"
@@ -167,6 +170,31 @@ struct JobBuilder {
 
 }  // namespace
 
+namespace {
+// The target forward (on s') and the policy forward (on s) are independent and each fills only part of
+// the chip at training batch sizes, so they run side by side: the target network goes to a helper
+// stream forked from / joined to the caller's stream with events (no host synchronisation; the pattern
+// is also legal under stream capture).  One helper stream and event pair per device, created on first
+// use and kept for the life of the process.
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+std::mutex g_side_mu;
+SideStream g_side[64];
+int side_stream(SideStream** out) {
+    int dev = 0;
+    MCTSQ_HIP(hipGetDevice(&dev));
+    MCTSQ_CHECK(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream& s = g_side[dev];
+    if (!s.st) {
+        MCTSQ_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        MCTSQ_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        MCTSQ_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    }
+    *out = &s;
+    return 0;
+}
+}  // namespace
+
 extern "C" int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
     NetLayout L;
     if (build_layout(net, &L)) return -1;
@@ -198,11 +226,17 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     float* ws = (float*)d_ws;
     const int64_t Bp = P.Bp;
 
-    // 1. target network on s' -> max_a' Q (dqn_per.py:460-463)
+    // 1. target network on s' -> max_a' Q (dqn_per.py:460-463), on the helper stream
+    SideStream* side = nullptr;
+    if (side_stream(&side)) return -1;
     {
+        MCTSQ_HIP(hipEventRecord(side->fork, st));
+        MCTSQ_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
         const float* x[3] = {d_nprice, d_nprocess, d_ngas};
         HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
-        if (forward_impl(L, d_target_params, nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, st, nullptr)) return -1;
+        if (forward_impl(L, d_target_params, nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, side->st, nullptr))
+            return -1;
+        MCTSQ_HIP(hipEventRecord(side->join, side->st));
     }
     // 2. policy network on s, activations kept (dqn_per.py:455-457)
     SlotSave sv[3];
@@ -238,6 +272,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         if (forward_impl(L, d_params, nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr)) return -1;
     }
     // 3. TD target, IS-weighted MSE, dLoss/dQ, new priorities (dqn_per.py:464-467, 474)
+    MCTSQ_HIP(hipStreamWaitEvent(st, side->join, 0));
     {
         TdArgs t;
         memset(&t, 0, sizeof(t));
