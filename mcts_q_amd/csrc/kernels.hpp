@@ -21,6 +21,7 @@ struct GruSlot {
     float* bw_g;                         // [S][Bp][256] = d(pre-activation) r | z | n | n*r
     float* bw_dsc;                       // [S][Bp] d(score)
     float* bw_p;                         // [Bp][64] dfeat * xhat (LayerNorm weight gradient terms)
+    float* bw_aw;                        // [Bp/16][65] per-tile partials of the score Linear(64,1) gradient
 };
 struct GruFwdArgs {
     GruSlot slot[3];

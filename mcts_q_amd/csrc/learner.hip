@@ -226,6 +226,12 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         }
     };
     fetch(cur, S - 1);
+    // gradient of the score Linear(64,1): d_aw[j] = sum_{t,row} dsc * h_t[row][j], d_ab = sum dsc.  h_t is
+    // the h_{t-1} operand of the step handled just before (the loop runs backwards); the tile's sums
+    // go out as one partial, reduced over tiles in order by wgrad_reduce_kernel.
+    float hnext[4], daw = 0.0f, dab = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hnext[r] = s.sv_h[((int64_t)S * Bp + row0 + 4 * q + r) * E + j];
     float dhc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int t = S - 1; t >= 0; --t) {
         const int buf = t & 1;
@@ -240,6 +246,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             const float4 pe = L.pe[t][i];
             const float dsc = at * (((pe.x + pe.y) + (pe.z + pe.w)) - Dd[r]);
             if (wq == 0 && jl == 0) s.bw_dsc[row] = dsc;
+            daw = fmaf(dsc, hnext[r], daw); dab += dsc;
+            hnext[r] = hprev;
             const float dh = dhc[r] + at * dpool[r] + dsc * awj;
             const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
             const float dzp = dh * (hprev - ng) * zg * (1.0f - zg);
@@ -269,6 +277,11 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             cur[r] = nxt[r];
         }
     }
+    daw += __shfl_xor(daw, 16, 64); daw += __shfl_xor(daw, 32, 64);
+    dab += __shfl_xor(dab, 16, 64); dab += __shfl_xor(dab, 32, 64);
+    float* pa = s.bw_aw + (row0 / TILE) * 65;
+    if (q == 0) pa[j] = daw;
+    if (wq == 0 && lane == 0) pa[64] = dab;
 }
 
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
@@ -276,6 +289,135 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
     MCTSQ_CHECK(a.Bp % TILE == 0, "padded batch must be a multiple of %d", TILE);
     for (int i = 0; i < a.nslots; ++i) MCTSQ_CHECK(a.slot[i].S <= MAX_SEQ, "window too long");
     hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)(a.Bp / TILE * a.nslots)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ================================================== GRU weight gradients (fused, one pass per slot)
+// Block = 4 waves, `rows` k-rows of one slot, walked in slabs of 32 rows staged through LDS (float4
+// loads, next slab in flight while the current one feeds the MFMAs).  Per 4-row k-step wave w issues
+// 15 MFMAs: [dr|dz] columns 32w..32w+31 against the four H tiles and the X tile (10), dn columns
+// 128+16w.. against X (1), dn*r columns 192+16w.. against the four H tiles (4); the A fragments'
+// column sums (bias gradients) ride along as VALU adds.  LDS row = 256 G | 64 H | 16 X floats; the
+// stride 336 = 16 (mod 64) keeps the operand reads of the 4 k-rows in disjoint bank groups.
+constexpr int GW_LD = 336, GW_KT = 32;
+__global__ __launch_bounds__(256) void gru_wgrad_kernel(GruWgradArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float gw_lds[];           // [2][GW_KT * GW_LD]
+    int si = 0;
+    for (int k = 1; k < args.nslots; ++k)
+        if ((int)blockIdx.x >= args.slot[k].blk0) si = k;
+    const GruWgradSlot& S = args.slot[si];
+    const int split = blockIdx.x - S.blk0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
+    const int k0 = split * S.rows, k1 = min(k0 + S.rows, S.K), F = S.F;
+    // staging roles: G 8 float4 per lane (row tid>>6 + 4p, cols 4*(tid&63)..), H 2 float4 (row tid>>4 + 16p,
+    // cols 4*(tid&15)..), X 1 float (row tid>>3, col tid&7)
+    const int gr = tid >> 6, gc = (tid & 63) * 4, hr = tid >> 4, hc = (tid & 15) * 4, xr = tid >> 3, xc = tid & 7;
+    f32x4 rg0, rg1, rg2, rg3, rg4, rg5, rg6, rg7, rh0, rh1;
+    float rx;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#define GW_LOADG(R, P) { const int k_ = kb_ + gr + 4 * (P); R = k_ < k1 ? *reinterpret_cast<const f32x4*>(S.G + (int64_t)k_ * 256 + gc) : z4; }
+#define GW_LOADH(R, P) { const int k_ = kb_ + hr + 16 * (P); R = k_ < k1 ? *reinterpret_cast<const f32x4*>(S.Hprev + (int64_t)k_ * E + hc) : z4; }
+#define GW_FETCH(KB) { const int kb_ = (KB); GW_LOADG(rg0, 0) GW_LOADG(rg1, 1) GW_LOADG(rg2, 2) GW_LOADG(rg3, 3) \
+        GW_LOADG(rg4, 4) GW_LOADG(rg5, 5) GW_LOADG(rg6, 6) GW_LOADG(rg7, 7) GW_LOADH(rh0, 0) GW_LOADH(rh1, 1) \
+        { const int k_ = kb_ + xr; rx = k_ < k1 ? S.X[(int64_t)k_ * 8 + xc] : 0.0f; } }
+#define GW_STG(R, P) *reinterpret_cast<f32x4*>(&Lb_[(gr + 4 * (P)) * GW_LD + gc]) = R;
+#define GW_STASH(BUF) { float* Lb_ = gw_lds + (BUF) * (GW_KT * GW_LD); GW_STG(rg0, 0) GW_STG(rg1, 1) GW_STG(rg2, 2) \
+        GW_STG(rg3, 3) GW_STG(rg4, 4) GW_STG(rg5, 5) GW_STG(rg6, 6) GW_STG(rg7, 7) \
+        *reinterpret_cast<f32x4*>(&Lb_[hr * GW_LD + 256 + hc]) = rh0; \
+        *reinterpret_cast<f32x4*>(&Lb_[(hr + 16) * GW_LD + 256 + hc]) = rh1; Lb_[xr * GW_LD + 320 + xc] = rx; }
+    // X tile columns 8..15 stay zero in both buffers
+    for (int i = tid; i < 2 * GW_KT * 8; i += 256) {
+        const int b = i / (GW_KT * 8), rr = (i >> 3) % GW_KT, cc = i & 7;
+        gw_lds[b * (GW_KT * GW_LD) + rr * GW_LD + 328 + cc] = 0.0f;
+    }
+    f32x4 arz[2][5], an = {0, 0, 0, 0}, anr[4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) arz[m][t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) anr[t] = f32x4{0, 0, 0, 0};
+    float bs0 = 0.f, bs1 = 0.f, bsn = 0.f, bsr = 0.f;
+    GW_FETCH(k0)
+    GW_STASH(0)
+    __syncthreads();
+    int buf = 0;
+    for (int kb = k0; kb < k1; kb += GW_KT) {
+        const bool more = kb + GW_KT < k1;
+        if (more) GW_FETCH(kb + GW_KT)
+        const float* Lb = gw_lds + buf * (GW_KT * GW_LD) + q * GW_LD + jl;
+#pragma unroll
+        for (int ks = 0; ks < GW_KT / 4; ++ks) {
+            const float* row = Lb + ks * 4 * GW_LD;
+            const float a0 = row[32 * w], a1 = row[32 * w + 16], a2 = row[128 + 16 * w], a3 = row[192 + 16 * w];
+            const float h0 = row[256], h1 = row[272], h2 = row[288], h3 = row[304], xv = row[320];
+            arz[0][0] = mfma16(a0, h0, arz[0][0]); arz[1][0] = mfma16(a1, h0, arz[1][0]); anr[0] = mfma16(a3, h0, anr[0]);
+            arz[0][1] = mfma16(a0, h1, arz[0][1]); arz[1][1] = mfma16(a1, h1, arz[1][1]); anr[1] = mfma16(a3, h1, anr[1]);
+            arz[0][2] = mfma16(a0, h2, arz[0][2]); arz[1][2] = mfma16(a1, h2, arz[1][2]); anr[2] = mfma16(a3, h2, anr[2]);
+            arz[0][3] = mfma16(a0, h3, arz[0][3]); arz[1][3] = mfma16(a1, h3, arz[1][3]); anr[3] = mfma16(a3, h3, anr[3]);
+            arz[0][4] = mfma16(a0, xv, arz[0][4]); arz[1][4] = mfma16(a1, xv, arz[1][4]); an = mfma16(a2, xv, an);
+            bs0 += a0; bs1 += a1; bsn += a2; bsr += a3;
+        }
+        if (more) GW_STASH(buf ^ 1)
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef GW_LOADG
+#undef GW_LOADH
+#undef GW_FETCH
+#undef GW_STG
+#undef GW_STASH
+    // ---- partials in the three WJob layouts: D register r of lane (jl, q) is [m = 4q + r][n = jl] ----
+    float* Pih = S.wp_ih + (int64_t)split * (G3 * F + G3);
+    float* Prz = S.wp_rz + (int64_t)split * (128 * E + 128);
+    float* Pn = S.wp_n + (int64_t)split * (E * E + E);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mm = 32 * w + 16 * m + 4 * q + r;                      // row of [dr|dz]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Prz[mm * E + 16 * t + jl] = arz[m][t][r];
+            if (jl < F) Pih[mm * F + jl] = arz[m][4][r];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int mm = 16 * w + 4 * q + r;
+        if (jl < F) Pih[(128 + mm) * F + jl] = an[r];                        // dn rows of W_ih
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Pn[mm * E + 16 * t + jl] = anr[t][r];
+    }
+    // bias column sums: fold the four k groups; lane jl of group 0 holds column jl of the fragment
+    bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
+    bsn += __shfl_xor(bsn, 16, 64); bsn += __shfl_xor(bsn, 32, 64);
+    bsr += __shfl_xor(bsr, 16, 64); bsr += __shfl_xor(bsr, 32, 64);
+    if (q == 0) {
+        Pih[G3 * F + 32 * w + jl] = bs0; Pih[G3 * F + 32 * w + 16 + jl] = bs1; Pih[G3 * F + 128 + 16 * w + jl] = bsn;
+        Prz[128 * E + 32 * w + jl] = bs0; Prz[128 * E + 32 * w + 16 + jl] = bs1;
+        Pn[E * E + 16 * w + jl] = bsr;
+    }
+}
+
+void gru_wgrad_geometry(int64_t K, int* rows, int* nsplit) {
+    int64_t r = (K + 255) / 256;                              // at most 256 blocks per slot
+    r = (r + GW_KT - 1) / GW_KT * GW_KT;
+    if (r < 160) r = 160;
+    *rows = (int)r;
+    *nsplit = (int)((K + r - 1) / r);
+}
+
+int launch_gru_wgrad(const GruWgradArgs& a, hipStream_t st) {
+    if (a.nslots == 0 || a.nblocks == 0) return 0;
+    const size_t lds = 2 * GW_KT * GW_LD * sizeof(float);     // 86 KB
+    static bool once = false;
+    if (!once) {
+        MCTSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_wgrad_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        once = true;
+    }
+    hipLaunchKernelGGL(gru_wgrad_kernel, dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -43,6 +43,23 @@ struct GruBwdArgs {
 };
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
 
+// ---- GRU weight gradients, all of one slot's big contractions in one pass over the saved tensors ----
+// dW_ih = [dr|dz|dn]^T X, dW_hh[0:128] = [dr|dz]^T H_prev, dW_hh[128:192] = (dn*r)^T H_prev and the
+// bias column sums, from G [K][256] = dr|dz|dn|dn*r (gru_bwd_kernel), H_prev [K][64], X [K][8].
+// Every block owns `rows` consecutive k-rows and writes one partial in the layout of three WJobs
+// ([M*N + M] each), reduced in block order by wgrad_reduce_kernel (bitwise reproducible).
+struct GruWgradSlot {
+    const float *G, *Hprev, *X;
+    float *wp_ih, *wp_rz, *wp_n;   // [nsplit][192*F + 192], [nsplit][128*64 + 128], [nsplit][64*64 + 64]
+    int K, F, rows, nsplit, blk0;
+};
+struct GruWgradArgs {
+    GruWgradSlot slot[3];
+    int nslots, nblocks;
+};
+void gru_wgrad_geometry(int64_t K, int* rows, int* nsplit);
+int launch_gru_wgrad(const GruWgradArgs& a, hipStream_t st);
+
 // ---- Conv-attention backward (enc_conv.hip) and gas/EUA MLP backward (enc_mlp.hip) ----
 struct ConvBwdArgs {
     ConvSlot slot[2];

@@ -26,6 +26,8 @@ struct Carver {
 struct SlotPlan {                      // float offsets; which fields are used depends on the kind
     int64_t score, stat, pool, x, dsc, p;
     int64_t h, r, z, n, hn, g;          // gru
+    int64_t wp_ih, wp_rz, wp_n, wp_aw;  // gru: partials of the fused weight-gradient kernel / of gru_bwd_kernel
+    int gw_rows, gw_nsplit;
     int64_t c_h1, c_h2, c_d2, c_d1;     // conv
     int64_t m_x, m_m0, m_d1, m_d0;      // mlp
     // transformer: [l] per layer
@@ -77,8 +79,13 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
             g.r = c.take(K * E); g.z = c.take(K * E); g.n = c.take(K * E); g.hn = c.take(K * E);
             g.score = c.take(K); g.stat = c.take(Bp * 4); g.pool = c.take(Bp * E); g.x = c.take(K * 8);
             g.g = c.take(K * 256); g.dsc = c.take(K); g.p = c.take(Bp * E);
-            pf += job_partial_floats(G3, e.F, K) + job_partial_floats(128, E, K) + job_partial_floats(E, E, K) +
-                  job_partial_floats(1, E, K) + 2 * job_partial_floats(E, 0, Bp);
+            MCTSQ_CHECK(K < ((int64_t)1 << 31), "batch too large");
+            gru_wgrad_geometry(K, &g.gw_rows, &g.gw_nsplit);
+            g.wp_ih = c.take((int64_t)g.gw_nsplit * (G3 * e.F + G3));
+            g.wp_rz = c.take((int64_t)g.gw_nsplit * (128 * E + 128));
+            g.wp_n = c.take((int64_t)g.gw_nsplit * (E * E + E));
+            g.wp_aw = c.take(Bp / TILE * 65);
+            pf += 2 * job_partial_floats(E, 0, Bp);
         } else if (e.kind == MCTSQ_ENC_CONV) {
             g.c_h1 = c.take((S + 2) * Bp * E); g.c_h2 = c.take(K * E);
             g.score = c.take(K); g.stat = c.take(Bp * 4); g.pool = c.take(Bp * E); g.x = c.take((S + 2) * Bp * 8);
@@ -247,6 +254,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         v.score = ws + g.score; v.stat = ws + g.stat; v.pool = ws + g.pool; v.x = ws + g.x; v.dsc = ws + g.dsc;
         v.p = ws + g.p;
         v.h = ws + g.h; v.r = ws + g.r; v.z = ws + g.z; v.n = ws + g.n; v.hn = ws + g.hn; v.g = ws + g.g;
+        v.aw = ws + g.wp_aw;
         v.c_h1 = ws + g.c_h1; v.c_h2 = ws + g.c_h2; v.c_d2 = ws + g.c_d2; v.c_d1 = ws + g.c_d1;
         v.m_x = ws + g.m_x; v.m_m0 = ws + g.m_m0; v.m_d1 = ws + g.m_d1; v.m_d0 = ws + g.m_d0;
         if (L.enc[s].kind == MCTSQ_ENC_TRANSFORMER) {
@@ -330,6 +338,8 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     }
     // 6. weight gradients: every tensor is one (or a few) K-contractions
     JobBuilder jb(ws);
+    GruWgradArgs gw;
+    memset(&gw, 0, sizeof(gw));
     for (int s = 0; s < 3; ++s) {
         const EncOff& e = L.enc[s];
         const SlotPlan& g = P.slot[s];
@@ -337,15 +347,22 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         if (e.kind == MCTSQ_ENC_GRU) {
             const float* G = ws + g.g;
             const float* Hprev = ws + g.h;                    // block t = h_{t-1}
-            const float* Hcur = ws + g.h + Bp * E;            // block t+1 = h_t
-            // W_ih [192][F] + b_ih: delta (r|z|n) x x_t
-            if (jb.add(G, 256, 0, ws + g.x, 8, 0, G3, e.F, K, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
-            // W_hh rows r,z + b_hh[0:128]: delta (r|z) x h_{t-1}
-            if (jb.add(G, 256, 0, Hprev, E, 0, 2 * E, E, K, e.gru.whh, E, 1, e.gru.bhh)) return -1;
-            // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1}
-            if (jb.add(G, 256, 3 * E, Hprev, E, 0, E, E, K, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E)) return -1;
-            // attention score Linear(64,1): d(score) x h_t
-            if (jb.add(ws + g.dsc, 1, 0, Hcur, E, 0, 1, E, K, e.gru.aw, E, 1, e.gru.ab)) return -1;
+            // W_ih [192][F] + b_ih: delta (r|z|n) x x_t;  W_hh rows r,z + b_hh[0:128]: delta (r|z) x h_{t-1};
+            // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1} -- one fused pass (gru_wgrad_kernel),
+            // reduced here in block order
+            {
+                GruWgradSlot& w = gw.slot[gw.nslots++];
+                w.G = G; w.Hprev = Hprev; w.X = ws + g.x; w.K = (int)K; w.F = e.F; w.rows = g.gw_rows;
+                w.nsplit = g.gw_nsplit; w.blk0 = gw.nblocks;
+                w.wp_ih = ws + g.wp_ih; w.wp_rz = ws + g.wp_rz; w.wp_n = ws + g.wp_n;
+                gw.nblocks += g.gw_nsplit;
+            }
+            if (jb.add_external(g.wp_ih - P.partials, G3, e.F, g.gw_nsplit, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
+            if (jb.add_external(g.wp_rz - P.partials, 2 * E, E, g.gw_nsplit, e.gru.whh, E, 1, e.gru.bhh)) return -1;
+            if (jb.add_external(g.wp_n - P.partials, E, E, g.gw_nsplit, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E))
+                return -1;
+            // attention score Linear(64,1): d(score) x h_t, per-tile partials written by gru_bwd_kernel
+            if (jb.add_external(g.wp_aw - P.partials, 1, E, (int)(Bp / TILE), e.gru.aw, E, 1, e.gru.ab)) return -1;
             // LayerNorm weight / bias: column sums over the batch
             if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1;
             if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
@@ -397,6 +414,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     }
     MCTSQ_CHECK(jb.part_pos <= P.partial_floats, "internal: partial buffer plan mismatch");
     MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), st));     // alignment pads stay zero
+    if (launch_gru_wgrad(gw, st)) return -1;
     for (int i = 0; i < jb.nlists; ++i)
         if (launch_wgrad(jb.lists[i], ws, ws + P.partials, st)) return -1;
     for (int i = 0; i < jb.nlists; ++i)
