@@ -78,10 +78,17 @@ int64_t forward_ws_floats(const NetLayout& L, int64_t Bp) {
     return n + prepared_bytes(L) / (int64_t)sizeof(float);
 }
 
-int64_t prepared_bytes(const NetLayout& L) {
+// layout of the prepared buffer: the GRU slots' fragments first (slot order), then 2 layers per
+// transformer slot
+static int64_t gru_prepared_bytes(const NetLayout& L) {
     int n = 0;
     for (int s = 0; s < 3; ++s) n += L.enc[s].kind == MCTSQ_ENC_GRU;
     return n * GRU_PREP_BYTES;
+}
+int64_t prepared_bytes(const NetLayout& L) {
+    int n = 0;
+    for (int s = 0; s < 3; ++s) n += L.enc[s].kind == MCTSQ_ENC_TRANSFORMER;
+    return gru_prepared_bytes(L) + 2 * n * TF_FFN_PREP_BYTES;
 }
 
 int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_t st) {
@@ -89,7 +96,17 @@ int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_
     int n = 0;
     for (int s = 0; s < 3; ++s)
         if (L.enc[s].kind == MCTSQ_ENC_GRU) whh[n++] = params + L.enc[s].gru.whh;
-    return launch_gru_prepare(whh, n, prep, st);
+    if (launch_gru_prepare(whh, n, prep, st)) return -1;
+    char* p = (char*)prep + gru_prepared_bytes(L);
+    for (int s = 0; s < 3; ++s) {
+        if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
+        for (int l = 0; l < 2; ++l) {
+            const TfLayerOff& o = L.enc[s].tfm.layer[l];
+            if (launch_tf_prepare(params + o.l1w, params + o.l2w, p, st)) return -1;
+            p += TF_FFN_PREP_BYTES;
+        }
+    }
+    return 0;
 }
 
 void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
@@ -156,10 +173,12 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     }
     {
         float* hbuf = ws + Bp * FEAT;
+        const char* tprep = (const char*)prep + gru_prepared_bytes(L);
         for (int s = 0; s < 2; ++s) {
             if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
             TfArgs t;
             fill_tf_args(t, L.enc[s], params, x[s], s, B, Bp, feats, hbuf, sv ? &sv[s] : nullptr);
+            for (int l = 0; l < 2; ++l) { t.ffn_prep[l] = tprep; tprep += TF_FFN_PREP_BYTES; }
             if (launch_tf_fwd(t, st)) return -1;
             hbuf += 2 * t.Tp * E;
         }

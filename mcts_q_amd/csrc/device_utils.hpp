@@ -32,6 +32,35 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2((2.0f * LOG2E) * x));
 }
 
+// ---- split-bf16 matrix arithmetic ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// D(16x16) += A(16x32) * B(32x16) on bf16 inputs, fp32 accumulate.  Lane l supplies A[row l&15][k = 8(l>>4)+e]
+// and B[k = 8(l>>4)+e][col l&15], e = 0..7 packed two per register; D layout as mfma16.
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// x = hi + mid + lo exactly, each part a bf16 (by truncation: every part takes the next 8 mantissa bits)
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    lo = __float_as_uint(r2) & 0xffff0000u;
+}
+// 8 consecutive fp32 -> three packed bf16x8 planes (element e in bits 16(e&1) of word e>>1)
+__device__ __forceinline__ void split8(const float4& x0, const float4& x1, u32x4& hi, u32x4& mid, u32x4& lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(x[2 * p], h0, m0, l0);
+        split3(x[2 * p + 1], h1, m1, l1);
+        hi[p] = (h0 >> 16) | h1; mid[p] = (m0 >> 16) | m1; lo[p] = (l0 >> 16) | l1;
+    }
+}
+
 // DPP move within rows of 16 lanes (row_ror:n = 0x120 + n)
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v) {

@@ -3,11 +3,7 @@
 //
 // Tokens are rows: token = sample*S + t, activations [tokens][64] fp32 in HBM between the stages
 //   embed -> { attention block -> FFN block } x 2 -> mean-pool + LayerNorm.
-// The FFN (94 % of the FLOPs) is the MFMA kernel that matters: each wave owns 64 tokens and walks
-// the 2048 hidden units 16 at a time; the hidden tile never leaves registers, because the D layout
-// of the first product (u^T = W1 . h^T: rows = hidden units, columns = tokens) is exactly the
-// A operand the second product (out = u . W2^T) wants.  Weight fragments stream from L2 (the two
-// FFN matrices are 1 MB per layer), activations never touch LDS.
+// The FFN (94 % of the FLOPs) is the MFMA kernel that matters: see tf_ffn_kernel.
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
@@ -220,66 +216,96 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
 }
 
 // ------------------------------------------------------------------------------------ FFN block
-// hout = LayerNorm2(hin + W2 relu(W1 hin + b1) + b2).  One wave = 64 tokens (4 tiles of 16).
+// hout = LayerNorm2(hin + W2 relu(W1 hin + b1) + b2).  One wave = 64 tokens (4 tiles of 16), one workgroup =
+// 4 waves.  The 2048 hidden units are walked 32 at a time ("pair" of 16-unit tiles); the hidden tile never
+// leaves registers: the D layout of the first product (u^T = W1 . h^T: rows = hidden units, columns =
+// tokens) is exactly the A operand the second product (out = u . W2^T) wants, with the k slots of the
+// 16x16x32 instruction assigned to the units a lane already holds (slot e of lane group q: unit 4q+e of the
+// first tile for e < 4, unit 16+4q+e-4 of the second) -- the prepared W2 fragments use the same order.
+// Both products run on the bf16 matrix instruction over the exact three-way split of their operands
+// (six cross terms, fp32 accumulate: DESIGN.md section 3): h is split once per wave, the weights once per
+// parameter change (tf_prepare_kernel), u after the ReLU.  The pair's 24 weight fragments (24 KB) are
+// fetched once per workgroup into double-buffered LDS and shared by its four waves.
+constexpr int FFN_FRAGS = 24, FFN_PAIRS = FF / 32;
+
+#define TF_MM6(ACC, XH, XM, XL, YH, YM, YL)                                              \
+    ACC = mfma_bf(XL, YH, ACC); ACC = mfma_bf(XH, YL, ACC); ACC = mfma_bf(XM, YM, ACC);   \
+    ACC = mfma_bf(XM, YH, ACC); ACC = mfma_bf(XH, YM, ACC); ACC = mfma_bf(XH, YH, ACC);
+
 __global__ __launch_bounds__(256) void tf_ffn_kernel(TfArgs a, int layer) {
+    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];        // 48 KB
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
     const float* hin = Bf.hmid;
     float* hout = Bf.hout;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, jl = lane & 15, q = lane >> 4;
-    const int64_t tok0 = ((int64_t)blockIdx.x * 4 + w) * TOK_PER_WAVE;
-    if (tok0 >= a.T) return;
-    // B operand of the first product: h^T, lane (token jl, k group q) holds h[token][16q .. 16q+15]
-    float hf[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
+    const int64_t tok0 = ((int64_t)blockIdx.x * 4 + w) * TOK_PER_WAVE;         // < Tp (grid = Tp / 256)
+    const u32x4* prep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]);
+    // B operand of the first product: h^T, lane (token jl, k group q) holds h[token][32c + 8q .. +7], split
+    u32x4 hh[4][2], hm[4][2], hl[4][2];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + 16 * tt + jl) * E + 16 * q);   // rows < Tp
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const float4 v = p[c]; hf[tt][4 * c] = v.x; hf[tt][4 * c + 1] = v.y; hf[tt][4 * c + 2] = v.z; hf[tt][4 * c + 3] = v.w; }
-    }
+        for (int c = 0; c < 2; ++c) {
+            const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + 16 * tt + jl) * E + 32 * c + 8 * q);
+            split8(p[0], p[1], hh[tt][c], hm[tt][c], hl[tt][c]);
+        }
     f32x4 acc[4][4];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[tt][c] = (f32x4){0, 0, 0, 0};
 
-    const float4* w1p = reinterpret_cast<const float4*>(W.l1w + (int64_t)jl * E + 16 * q);        // + nt * 16 rows
-    const float* w2p = W.l2w + (int64_t)jl * FF + 4 * q;                                            // + c*16 rows, + nt*16
+    u32x4 stg[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) stg[i] = prep[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wl[0][tid + 256 * i] = stg[i];
     const float* b1p = W.l1b + 4 * q;
-    float4 w1n[4], w2n[4], b1n;
+    float4 b1n0 = *reinterpret_cast<const float4*>(b1p), b1n1 = *reinterpret_cast<const float4*>(b1p + 16);
+    __syncthreads();
+    for (int pr = 0; pr < FFN_PAIRS; ++pr) {
+        const int buf = pr & 1;
+        const float4 b10 = b1n0, b11 = b1n1;
+        if (pr + 1 < FFN_PAIRS) {                                   // next pair's fragments and biases in flight
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { w1n[c] = w1p[c]; w2n[c] = *reinterpret_cast<const float4*>(w2p + (int64_t)c * 16 * FF); }
-    b1n = *reinterpret_cast<const float4*>(b1p);
-    for (int nt = 0; nt < FF / 16; ++nt) {
-        float4 w1c[4], w2c[4];
-        const float4 b1c = b1n;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { w1c[c] = w1n[c]; w2c[c] = w2n[c]; }
-        if (nt + 1 < FF / 16) {                                     // prefetch the next hidden tile's fragments
-            const float4* np1 = w1p + (int64_t)(nt + 1) * 16 * (E / 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                w1n[c] = np1[c];
-                w2n[c] = *reinterpret_cast<const float4*>(w2p + (int64_t)c * 16 * FF + (nt + 1) * 16);
-            }
-            b1n = *reinterpret_cast<const float4*>(b1p + (nt + 1) * 16);
+            for (int i = 0; i < 6; ++i) stg[i] = prep[(int64_t)(pr + 1) * (FFN_FRAGS * 64) + tid + 256 * i];
+            b1n0 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32);
+            b1n1 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32 + 16);
         }
+        const u32x4* wf = &wl[buf][lane];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            f32x4 u = {b1c.x, b1c.y, b1c.z, b1c.w};                 // bias of hidden unit 4q + r
+            // ---- u^T = W1 . h^T for the pair's two unit tiles (bias of hidden unit 4q + r preloaded) ----
+            f32x4 ua = {b10.x, b10.y, b10.z, b10.w}, ub = {b11.x, b11.y, b11.z, b11.w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                u = mfma16(w1c[c].x, hf[tt][4 * c + 0], u); u = mfma16(w1c[c].y, hf[tt][4 * c + 1], u);
-                u = mfma16(w1c[c].z, hf[tt][4 * c + 2], u); u = mfma16(w1c[c].w, hf[tt][4 * c + 3], u);
+            for (int c = 0; c < 2; ++c) {
+                const u32x4 ah = wf[((0 * 2 + c) * 3 + 0) * 64], am = wf[((0 * 2 + c) * 3 + 1) * 64], al = wf[((0 * 2 + c) * 3 + 2) * 64];
+                const u32x4 bh = wf[((1 * 2 + c) * 3 + 0) * 64], bm = wf[((1 * 2 + c) * 3 + 1) * 64], bl = wf[((1 * 2 + c) * 3 + 2) * 64];
+                TF_MM6(ua, ah, am, al, hh[tt][c], hm[tt][c], hl[tt][c])
+                TF_MM6(ub, bh, bm, bl, hh[tt][c], hm[tt][c], hl[tt][c])
             }
-            const float u0 = fmaxf(u[0], 0.0f), u1 = fmaxf(u[1], 0.0f), u2 = fmaxf(u[2], 0.0f), u3 = fmaxf(u[3], 0.0f);
+            // ---- ReLU, split: the lane's 8 values are k slots 0..7 of the second product ----
+            u32x4 uh, um, ul;
+            {
+                const float4 v0 = make_float4(fmaxf(ua[0], 0.0f), fmaxf(ua[1], 0.0f), fmaxf(ua[2], 0.0f), fmaxf(ua[3], 0.0f));
+                const float4 v1 = make_float4(fmaxf(ub[0], 0.0f), fmaxf(ub[1], 0.0f), fmaxf(ub[2], 0.0f), fmaxf(ub[3], 0.0f));
+                split8(v0, v1, uh, um, ul);
+            }
+            // ---- out += u . W2^T ----
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                acc[tt][c] = mfma16(u0, w2c[c].x, acc[tt][c]); acc[tt][c] = mfma16(u1, w2c[c].y, acc[tt][c]);
-                acc[tt][c] = mfma16(u2, w2c[c].z, acc[tt][c]); acc[tt][c] = mfma16(u3, w2c[c].w, acc[tt][c]);
+                const u32x4 yh = wf[(12 + c * 3 + 0) * 64], ym = wf[(12 + c * 3 + 1) * 64], yl = wf[(12 + c * 3 + 2) * 64];
+                TF_MM6(acc[tt][c], uh, um, ul, yh, ym, yl)
             }
         }
+        if (pr + 1 < FFN_PAIRS) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) wl[buf ^ 1][tid + 256 * i] = stg[i];
+        }
+        __syncthreads();
     }
+    if (tok0 >= a.T) return;
     // ---- + b2 + residual, LayerNorm2 -------------------------------------------------------------
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
@@ -327,6 +353,39 @@ __global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) {
     a.feats[b * FEAT + a.out_col + lane] = v;
 }
 
+// FFN weights -> split-bf16 fragments: one thread per (pair, fragment group, lane); fragment order as
+// read by tf_ffn_kernel: W1 [unit tile m 2][K chunk c 2][plane 3], then W2 [out tile n 4][plane 3].
+__global__ __launch_bounds__(256) void tf_prepare_kernel(const float* __restrict__ l1w, const float* __restrict__ l2w,
+                                                        u32x4* __restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;           // FFN_PAIRS * 8 * 64 threads
+    const int lane = gid & 63, grp = (gid >> 6) & 7, pr = gid >> 9;
+    const int jl = lane & 15, q = lane >> 4;
+    float4 v0, v1;
+    int f0;
+    if (grp < 4) {                                            // W1: unit tile m, K chunk c
+        const int m = grp >> 1, c = grp & 1;
+        const float4* p = reinterpret_cast<const float4*>(l1w + (int64_t)(32 * pr + 16 * m + jl) * E + 32 * c + 8 * q);
+        v0 = p[0]; v1 = p[1];
+        f0 = (m * 2 + c) * 3;
+    } else {                                                  // W2: output tile n; k slot e -> unit 4q+e | 16+4q+e-4
+        const int n = grp - 4;
+        const float* p = l2w + (int64_t)(16 * n + jl) * FF + 32 * pr + 4 * q;
+        v0 = *reinterpret_cast<const float4*>(p); v1 = *reinterpret_cast<const float4*>(p + 16);
+        f0 = 12 + n * 3;
+    }
+    u32x4 hi, mid, lo;
+    split8(v0, v1, hi, mid, lo);
+    u32x4* o = out + (int64_t)pr * (FFN_FRAGS * 64) + lane;
+    o[(f0 + 0) * 64] = hi; o[(f0 + 1) * 64] = mid; o[(f0 + 2) * 64] = lo;
+}
+
+int launch_tf_prepare(const float* l1w, const float* l2w, void* prep, hipStream_t st) {
+    hipLaunchKernelGGL(tf_prepare_kernel, dim3(FFN_PAIRS * 8 * 64 / 256), dim3(256), 0, st, l1w, l2w,
+                       reinterpret_cast<u32x4*>(prep));
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int64_t tf_padded_tokens(int64_t B, int S) { return round_up(B * S, TOK_PER_WG); }
 
 int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
@@ -334,6 +393,7 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
     MCTSQ_CHECK(a.S >= 1 && a.S <= 32, "transformer encoder: seq_len %d outside 1..32", a.S);
     MCTSQ_CHECK(a.Tp % TOK_PER_WG == 0 && a.Tp >= a.T && a.T == a.B * a.S, "transformer encoder: bad token padding");
     MCTSQ_CHECK(a.NS >= 1 && a.NS * a.S <= AROWS, "transformer encoder: samples per workgroup");
+    MCTSQ_CHECK(a.ffn_prep[0] && a.ffn_prep[1], "transformer encoder needs prepared FFN weights");
     hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp * E / 256)), dim3(256), 0, st, a);
     const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / TOK_PER_WG);
     for (int l = 0; l < 2; ++l) {

@@ -100,9 +100,14 @@ struct TfArgs {
     float* feats;                        // [Bp][192]
     float* sv_mean;                      // training: [Bp][64] mean over time before the final LayerNorm
     float* sv_xe;                        // training: [Tp][8] embedded-input rows incl. time features
+    const void* ffn_prep[2];             // per layer: FFN weights as split-bf16 fragments (tf_prepare_kernel)
 };
 int64_t tf_padded_tokens(int64_t B, int S);
 int launch_tf_fwd(const TfArgs& a, hipStream_t st);
+// FFN weights of one layer (linear1 [2048][64], linear2 [64][2048]) -> split-bf16 fragments in the
+// order tf_ffn_kernel consumes them: u32x4 [pair of hidden tiles 64][fragment 24][lane 64]
+constexpr int64_t TF_FFN_PREP_BYTES = 64 * 24 * 64 * 16;
+int launch_tf_prepare(const float* l1w, const float* l2w, void* prep, hipStream_t st);
 
 // ---------------- head ----------------
 struct HeadArgs {
