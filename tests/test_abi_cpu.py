@@ -1,0 +1,40 @@
+"""The C-ABI library loads without a GPU and exports every entry point include/mctsq_hip.h declares; the
+ctypes table (mcts_q_amd/_lib.py) covers the same set.  No compute calls here."""
+import ctypes
+import os
+import re
+
+from mcts_q_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mctsq_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mctsq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 25
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(dll, n)]
+    assert not missing, missing
+    assert dll.mctsq_abi_version() == 2
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_host_side_queries_need_no_gpu():
+    from mcts_q_amd import NetSpec
+    spec = NetSpec.from_cfg(dict(price="gru", process="gru", gas="gru", act="relu", flavor="per"))
+    d = spec.c_desc()
+    lib = _lib.lib
+    assert lib.mctsq_q_prepared_bytes(ctypes.byref(d)) == 3 * 4 * 3 * 2 * 3 * 64 * 16
+    assert lib.mctsq_q_forward_workspace_bytes(ctypes.byref(d), 4096) > 4096 * 192 * 4
+    assert lib.mctsq_per_tree_words(1_000_000) > 1_000_000
+    assert lib.mctsq_q_forward_workspace_bytes(ctypes.byref(d), -1) < 0
+    assert b"negative" in lib.mctsq_last_error()
