@@ -3,9 +3,8 @@
 // (mcts_per.py:293, 370).  One workgroup = one 16-sample tile = 8 waves (two per SIMD, 256 VGPRs each):
 //   waves 0-3  the longest window (price, 25 steps), waves 4-7 the other two back to back (10 + 3).
 // Each 4-wave group synchronises through its own LDS arrival counter (gru_core.hpp), not the
-// workgroup barrier: the price recurrence is the critical path and runs at raised issue priority
-// while the shorter windows fill the gaps its gate math and h exchange leave.  Waves 0-3 then fetch
-// the head's weight fragments straight into VGPRs while the price recurrence is still running;
+// workgroup barrier, so the shorter windows fill the gaps the long one's gate math and h exchange
+// leave.  Waves 0-3 then fetch the head's weight fragments straight into VGPRs while group 1 finishes;
 // the feature rows never leave LDS and the head needs no second launch.
 #include "gru_core.hpp"
 
@@ -22,10 +21,6 @@ __device__ long long g_iter[192];
 #else
 #define STAMP(k) do {} while (0)
 #define WSTAMP(k) do {} while (0)
-#endif
-
-#ifndef MCTSQ_PRIO
-#define MCTSQ_PRIO 0
 #endif
 
 struct FusedLds {
@@ -67,8 +62,8 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     const int jl = lane & 15, q = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * TILE;
     GruLds& G = L.g[grp];
-    // group 0 takes the longest window (the critical path, raised issue priority); group 1 runs the
-    // other two back to back in the gaps the first leaves on each SIMD
+    // group 0 takes the longest window; group 1 runs the other two back to back on the same SIMDs (issue
+    // priorities were measured to make no difference: the two waves of a SIMD share it evenly)
     const int S0 = ga.slot[0].S, S1 = ga.slot[1].S, S2 = ga.slot[2].S;
     const int big = (S0 >= S1 && S0 >= S2) ? 0 : (S1 >= S2 ? 1 : 2);
     const int sa = grp == 0 ? big : (big == 0 ? 1 : 0);
@@ -77,7 +72,6 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     STAMP(0);
     GruWave<SAVE> g;
     g.bind(lane, wq);
-    if (grp == 0) __builtin_amdgcn_s_setprio(MCTSQ_PRIO);
     if ((MCTSQ_EXP & 8) && grp == 1) __syncthreads();  // ablation: long window only
     else run_window<SAVE>(g, ga.slot[sa], G, L.feats, gtid, row0, ga.B, ga.Bp, true);
     STAMP(1);
@@ -85,7 +79,6 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         g.sync(G);                                    // every wave is done with the first window's LDS
         run_window<SAVE>(g, ga.slot[sb], G, L.feats, gtid, row0, ga.B, ga.Bp, false);
     }
-    __builtin_amdgcn_s_setprio(0);
     // The GRU registers are dead from here on.  Group 0 finishes first (25 steps against 10 + 3 and a
     // second staging): its waves fetch the head's weight fragments (two 16-column tiles of layers 0
     // and 1 each; wave 0 also the output layer) while group 1 is still stepping:
