@@ -200,35 +200,73 @@ class LockstepAgent:
     (data-parallel over ranks when the DQNModel's learner has a process group)."""
 
     def __init__(self, envs, dqn: DQNModel, iterations: int, maximum_depth: int, c_base: float, c_init: float,
-                 tau: float = 0.005, tree_remain_interval: int = 10, seed: int = 0, updates_per_step: int = 1):
-        self.envs, self.dqn, self.K = list(envs), dqn, len(envs)
+                 tau: float = 0.005, tree_remain_interval: int = 10, seed: int = 0, updates_per_step: int = 1,
+                 batch_env=None, n_trees: int | None = None):
+        """envs: K environments with the `_per` protocol, OR batch_env (+ n_trees): one vectorised environment
+        with the batched protocol of treesearch.LockstepMCTS (reset(seeds), observe, step_batch)."""
+        self.dqn, self.batch_env = dqn, batch_env
         self.tau, self.tree_remain_interval, self.updates_per_step = tau, tree_remain_interval, updates_per_step
+        self.step_count, self.leaf_evals = 0, 0
+        if batch_env is not None:
+            self.K = int(n_trees)
+            self.search = LockstepMCTS(self.K, _device_evaluator(dqn.policy_net), iterations, maximum_depth, c_base,
+                                       c_init, batch_env=batch_env, seed=seed)
+            self._episode = np.arange(self.K, dtype=np.int64)
+            self.states = batch_env.reset(self._episode + seed * 1000003)
+            self.rows, _ = batch_env.observe(self.states)
+            self.keep = np.zeros(self.K, dtype=bool)
+            return
+        self.envs, self.K = list(envs), len(envs)
         self.search = LockstepMCTS(self.K, _device_evaluator(dqn.policy_net), iterations, maximum_depth, c_base,
                                    c_init, rngs=[random.Random(seed * 1000003 + i) for i in range(self.K)])
         res = [e.reset() for e in self.envs]
         self.obs = [r[0] for r in res]
         self.state_c = [r[1]['state_c'] for r in res]
         self.keep = np.zeros(self.K, dtype=bool)
-        self.step_count, self.leaf_evals = 0, 0
+
+    def _step_batch(self, train: bool):
+        K, benv, buf = self.K, self.batch_env, self.dqn.replay_buffer
+        n0 = self.search.n
+
+        def push_rows(rows, acts, rew, nrows, done):
+            buf.flush()
+            buf.dev.push_rows(rows, np.asarray(acts, dtype=np.int32), np.asarray(rew, dtype=np.float32), nrows,
+                              np.asarray(done, dtype=np.float32))
+        actions = self.search.predict(self.states, train=train, reuse=self.keep, push_rows=push_rows if train else None)
+        self.leaf_evals += K * self.search.iterations + (n0 if train else 0) + K
+        nst, nrows, rew, term, _, _ = benv.step_batch(self.states, actions)
+        if train:
+            push_rows(self.rows, actions, rew, nrows, term)
+        if term.any():                                    # episode ends: fresh episodes for those trees
+            idx = np.nonzero(term)[0]
+            self._episode[idx] += K
+            nst[idx] = benv.reset(self._episode[idx])
+            nrows[idx] = benv.observe(nst[idx])[0]
+        self.states, self.rows = nst, nrows
+        return actions, rew, term
 
     def step(self, train: bool = True):
         """One environment step of every tree; returns (actions, rewards, loss of the last update)."""
-        K, envs = self.K, self.envs
-        push = self.dqn.replay_buffer.push if train else None
-        n0 = self.search.n
-        actions = self.search.predict(self.state_c, lambda i, a, sc: envs[i].step([a, sc]), train=train, push=push,
-                                      reuse=self.keep)
-        self.leaf_evals += K * self.search.iterations + (n0 if train else 0) + K
-        rewards = np.zeros(K)
-        term = np.zeros(K, dtype=bool)
-        for i in range(K):
-            nobs, rewards[i], term[i], _, info = envs[i].step([int(actions[i]), self.state_c[i]])
-            if train:
-                self.dqn.replay_buffer.push(self.obs[i], int(actions[i]), rewards[i], nobs, bool(term[i]))
-            self.obs[i], self.state_c[i] = nobs, info['state_c']
-            if term[i]:
-                self.obs[i], info = envs[i].reset()
-                self.state_c[i] = info['state_c']
+        K = self.K
+        if self.batch_env is not None:
+            actions, rewards, term = self._step_batch(train)
+        else:
+            envs = self.envs
+            push = self.dqn.replay_buffer.push if train else None
+            n0 = self.search.n
+            actions = self.search.predict(self.state_c, lambda i, a, sc: envs[i].step([a, sc]), train=train, push=push,
+                                          reuse=self.keep)
+            self.leaf_evals += K * self.search.iterations + (n0 if train else 0) + K
+            rewards = np.zeros(K)
+            term = np.zeros(K, dtype=bool)
+            for i in range(K):
+                nobs, rewards[i], term[i], _, info = envs[i].step([int(actions[i]), self.state_c[i]])
+                if train:
+                    self.dqn.replay_buffer.push(self.obs[i], int(actions[i]), rewards[i], nobs, bool(term[i]))
+                self.obs[i], self.state_c[i] = nobs, info['state_c']
+                if term[i]:
+                    self.obs[i], info = envs[i].reset()
+                    self.state_c[i] = info['state_c']
         loss = None
         if train:
             for _ in range(self.updates_per_step):

@@ -53,3 +53,43 @@ class FakeGymEnv(FakePerEnv):
         super().__init__(seed, horizon)
         self.action_space = _Discrete(5)
         self.eps_sim_steps = eps_sim_steps
+
+
+class FakeBatchEnv:
+    """Vectorised synthetic environment for the batched-environment protocol of treesearch.LockstepMCTS:
+    state vector = (hash, t, meth_state, cumulative reward); observations are a counter-based hash of the
+    state, so step_batch is a pure function of (states, actions) like the `_per` environment."""
+    state_dim = 4
+
+    def __init__(self, horizon=1000):
+        self.horizon = horizon
+        self._lanes = (np.arange(91, dtype=np.uint64) + 1) * np.uint64(0x9E3779B97F4A7C15)
+
+    def reset(self, seeds):
+        seeds = np.asarray(seeds, dtype=np.uint64)
+        st = np.zeros((len(seeds), 4))
+        st[:, 0] = ((seeds * np.uint64(1000003) + np.uint64(12345)) & np.uint64(0x7fffffff)).astype(np.float64)
+        return st
+
+    def _rows(self, h):
+        x = (h.astype(np.uint64)[:, None] + np.uint64(1)) * self._lanes[None, :]
+        x ^= x >> np.uint64(29)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(32)
+        return ((x >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24)))
+
+    def observe(self, states):
+        states = np.asarray(states)
+        return self._rows(states[:, 0]), states[:, 2].astype(np.int64)
+
+    def step_batch(self, states, actions):
+        states = np.asarray(states)
+        a = np.asarray(actions, dtype=np.uint64)
+        h = states[:, 0].astype(np.uint64)
+        h = (h * np.uint64(6364136223846793005) + np.uint64(1442695040888963407) * (a + np.uint64(1)))
+        h = (h >> np.uint64(16)) & np.uint64(0x7fffffff)
+        reward = ((h >> np.uint64(3)) % np.uint64(2001)).astype(np.float64) / 1000.0 - 1.0
+        t = states[:, 1] + 1
+        nxt = np.stack([h.astype(np.float64), t, a.astype(np.float64), states[:, 3] + reward], axis=1)
+        term = t >= self.horizon
+        return nxt, self._rows(h), reward, term, np.zeros(len(t), dtype=bool), a.astype(np.int64)

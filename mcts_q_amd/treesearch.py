@@ -34,6 +34,9 @@ N_ACT = 5
 _LEGAL = {0: 0b00111, 1: 0b00111, 2: 0b11011, 3: 0b11011, 4: 0b11011}
 _ALL = 0b11111
 _ACTIONS_OF = [[a for a in range(N_ACT) if m >> a & 1] for m in range(32)]
+_NBITS = np.array([len(a) for a in _ACTIONS_OF], dtype=np.int64)
+_KTH = np.array([(a + [0] * N_ACT)[:N_ACT] for a in _ACTIONS_OF], dtype=np.int64)      # k-th set bit of a mask
+_LEGAL_TAB = np.array([_LEGAL.get(m, _ALL) for m in range(8)], dtype=np.int64)
 
 
 def legal_mask(meth_state) -> int:
@@ -52,10 +55,21 @@ class LockstepMCTS:
     protocol, a pure function of (action, state_c) with info['state_c'] the successor (ptg_gym_env_per.py:422-431).
     push(state, action, reward, next_state, terminated): replay sink for transitions met while expanding in
     training mode (mcts_per.py:336-340), or None.
+
+    Batched-environment mode (batch_env given): the per-tree Python calls above are
+    the host bottleneck, so an environment that can step many states at once plugs in through
+        batch_env.state_dim                          -> D, length of one state vector (float64)
+        batch_env.observe(states [n, D])             -> rows fp32 [n, 91], meth_state int [n]
+        batch_env.step_batch(states [n, D], actions) -> next_states [n, D], rows fp32 [n, 91], reward [n],
+                                                        terminated [n], truncated [n], meth_state int [n]
+    and the driver keeps state vectors instead of state_c dicts; predict() then takes states [K, D], the
+    untried action is drawn from ONE numpy generator for all trees (same distribution as random.choice, not
+    the same stream), and transitions go to push_rows(rows, actions, rewards, next_rows, dones) in one call
+    per iteration.
     """
 
     def __init__(self, n_trees: int, evaluate, iterations: int, maximum_depth: int, c_base: float, c_init: float,
-                 rngs=None):
+                 rngs=None, batch_env=None, seed: int = 0):
         self.K = int(n_trees)
         self.evaluate = evaluate
         self.iterations = int(iterations)
@@ -64,6 +78,9 @@ class LockstepMCTS:
         # one random stream per tree; None = the global `random` module, as the reference uses (:328)
         self.rngs = list(rngs) if rngs is not None else [random] * self.K
         assert len(self.rngs) == self.K
+        self.batch_env = batch_env
+        self.D = int(batch_env.state_dim) if batch_env is not None else 0
+        self.np_rng = np.random.default_rng(seed)
         self.root = np.full(self.K, -1, dtype=np.int64)
         self.treedepth = np.zeros(self.K, dtype=np.int64)
         self._alloc(0)
@@ -86,6 +103,7 @@ class LockstepMCTS:
         self.vmax = np.zeros(cap, dtype=np.float64)
         self.prior_a = np.zeros(cap, dtype=np.float64)
         self.rows = np.zeros((cap, ROW), dtype=np.float32)
+        self.svec = np.zeros((cap, self.D), dtype=np.float64)       # batched-environment mode: state vectors
         self.state_c = [None] * cap
         self.extra = [None] * cap           # (meth_state_tr, el_price_tr, pot_reward_tr) of mcts_per.py:351-353
 
@@ -97,7 +115,7 @@ class LockstepMCTS:
         self._alloc(cap)
         n = old["n"] if "n" in old else 0
         for k in ("parent", "action", "visits", "total", "depth", "done", "legal", "tried", "nchild", "child",
-                  "vmax", "prior_a", "rows"):
+                  "vmax", "prior_a", "rows", "svec"):
             getattr(self, k)[:n] = old[k][:n]
         self.state_c[:n] = old["state_c"][:n]
         self.extra[:n] = old["extra"][:n]
@@ -119,6 +137,22 @@ class LockstepMCTS:
             self.extra[i] = extras[j] if extras is not None else None
             self.legal[i] = legal_mask(sc['Meth_State'])
             self.rows[i] = obs_to_row(sc['obs_norm'])
+        return ids
+
+    def _new_nodes_batch(self, svec, rows, meth, parents, actions, dones, depths):
+        """Batched-environment form of _new_nodes: no per-node Python."""
+        m = len(svec)
+        self._grow(self.n + m)
+        ids = np.arange(self.n, self.n + m)
+        self.n += m
+        self.parent[ids], self.action[ids] = parents, actions
+        self.visits[ids], self.total[ids] = 0, 0.0
+        self.depth[ids], self.done[ids] = depths, dones
+        self.tried[ids], self.nchild[ids] = 0, 0
+        self.child[ids] = -1
+        self.svec[ids], self.rows[ids] = svec, rows
+        meth = np.asarray(meth, dtype=np.int64)
+        self.legal[ids] = np.where((meth >= 0) & (meth < 8), _LEGAL_TAB[np.clip(meth, 0, 7)], _ALL)
         return ids
 
     def _c_puct(self, tv):
@@ -159,7 +193,7 @@ class LockstepMCTS:
         old_ids = np.nonzero(mark)[0]
         remap = np.full(self.n + 1, -1, dtype=np.int64)           # remap[-1] stays -1
         remap[old_ids] = np.arange(len(old_ids))
-        for k in ("action", "visits", "total", "done", "legal", "tried", "nchild", "vmax", "prior_a", "rows"):
+        for k in ("action", "visits", "total", "done", "legal", "tried", "nchild", "vmax", "prior_a", "rows", "svec"):
             arr = getattr(self, k)
             arr[:len(old_ids)] = arr[old_ids]
         self.depth[:len(old_ids)] = rel[old_ids]                 # reset_depths (:239-243)
@@ -175,16 +209,13 @@ class LockstepMCTS:
     def advance(self, actions, keep=None):
         """After the environment took `actions`: the matching child becomes the next root (:154-165);
         trees with keep[i] False (episode end, tree_remain interval, validation) start fresh."""
-        nxt = np.full(self.K, -1, dtype=np.int64)
-        for i in range(self.K):
-            r = self.root[i]
-            if r < 0 or (keep is not None and not keep[i]):
-                continue
-            for s in range(self.nchild[r]):
-                c = self.child[r, s]
-                if self.action[c] == actions[i]:
-                    nxt[i] = c
-                    break
+        actions = np.asarray(actions, dtype=np.int64)
+        ok = self.root >= 0
+        if keep is not None:
+            ok &= np.asarray(keep, dtype=bool)
+        ch = self.child[np.where(ok, self.root, 0)]                       # [K, 5]
+        hit = (ch >= 0) & (self.action[np.where(ch >= 0, ch, 0)] == actions[:, None]) & ok[:, None]
+        nxt = np.where(hit.any(1), ch[np.arange(self.K), np.argmax(hit, axis=1)], -1)
         self.root = self._retain(nxt)
 
     def reset(self, mask=None):
@@ -197,10 +228,12 @@ class LockstepMCTS:
         self.root = self._retain(keep)
 
     # ---- the search ---------------------------------------------------------------------------
-    def predict(self, state_cs, env_step, train: bool = True, push=None, reuse=None):
+    def predict(self, state_cs, env_step=None, train: bool = True, push=None, reuse=None, push_rows=None):
         """One MCTS search per tree from state_cs[i]; returns the most-visited root action of every tree
-        (int64 [K]).  reuse[i] True keeps tree i's retained sub-tree (if advance() left one)."""
+        (int64 [K]).  reuse[i] True keeps tree i's retained sub-tree (if advance() left one).  In
+        batched-environment mode state_cs is the [K, D] state array and env_step is unused."""
         K = self.K
+        benv = self.batch_env
         assert len(state_cs) == K
         self.treedepth[:] = 0
         keep = self.root.copy()
@@ -210,7 +243,11 @@ class LockstepMCTS:
             keep[~np.asarray(reuse, dtype=bool)] = -1
         self.root = self._retain(keep)
         fresh = np.nonzero(self.root < 0)[0]
-        if len(fresh):
+        if len(fresh) and benv is not None:
+            sv = np.asarray(state_cs, dtype=np.float64)[fresh]
+            rows, meth = benv.observe(sv)
+            self.root[fresh] = self._new_nodes_batch(sv, rows, meth, -1, -1, False, 0)
+        elif len(fresh):
             ids = self._new_nodes([state_cs[i] for i in fresh], -1, -1, False, 0)
             self.root[fresh] = ids
         self._evaluate_nodes(np.arange(self.n))        # fresh roots + retained sub-trees under the current weights
@@ -240,7 +277,23 @@ class LockstepMCTS:
             # -- expansion (:312-356)
             terminal = self.done[cur] | (self.depth[cur] >= maxd)
             exp = trees[~terminal]
-            if len(exp):
+            if len(exp) and benv is not None:
+                par = cur[exp]
+                mask = self.legal[par] & ~self.tried[par] & _ALL
+                k = np.minimum((self.np_rng.random(len(exp)) * _NBITS[mask]).astype(np.int64), _NBITS[mask] - 1)
+                acts = _KTH[mask, k]
+                nsv, rows, rew, term, trunc, meth = benv.step_batch(self.svec[par], acts)
+                if train and push_rows is not None:
+                    push_rows(rows, acts, rew, rows, term)                # state == next state here (:337-340)
+                ids = self._new_nodes_batch(nsv, rows, meth, par, acts, np.asarray(term, dtype=bool) | np.asarray(trunc, dtype=bool),
+                                            self.depth[par] + 1)
+                self.child[par, self.nchild[par]] = ids
+                self.nchild[par] += 1
+                self.tried[par] |= 1 << acts
+                self.treedepth[exp] = np.maximum(self.treedepth[exp], self.depth[ids])
+                cur[exp] = ids
+                self._evaluate_nodes(ids)
+            elif len(exp):
                 scs, acts, dones, extras = [], [], [], []
                 for i in exp:
                     node = cur[i]

@@ -103,3 +103,23 @@ def test_lockstep_agent_many_trees_one_learner():
     # root transition + at most one expansion per iteration and tree (terminal leaves are not expanded)
     assert 8 * K < len(dqn.replay_buffer) <= 8 * K * (1 + 10)
     assert losses and np.isfinite(losses).all()
+
+
+def test_lockstep_agent_batched_environment():
+    from mcts_q_amd.dqn import DQNModel
+    from mcts_q_amd.mcts import LockstepAgent
+    from mcts_q_amd.synthetic_env import FakeBatchEnv
+    dqn = DQNModel(1, 6, 2, 5, 64, 2, 128, buffer_capacity=50000, batch_size=64, gamma=0.99, lr=1e-3,
+                   price_encoder_type="gru", process_encoder_type="gru", gas_eua_encoder_type="gru",
+                   learning_starts=64, seed=1)
+    K = 64
+    agent = LockstepAgent(None, dqn, iterations=10, maximum_depth=42, c_base=19652, c_init=1.25,
+                          tree_remain_interval=3, batch_env=FakeBatchEnv(horizon=5), n_trees=K)
+    losses = []
+    for _ in range(7):
+        acts, rew, loss = agent.step()
+        assert acts.shape == (K,) and ((0 <= acts) & (acts < 5)).all()
+        if loss is not None:
+            losses.append(float(loss))
+    assert 7 * K < len(dqn.replay_buffer) <= 7 * K * 11
+    assert losses and np.isfinite(losses).all()

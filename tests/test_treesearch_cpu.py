@@ -108,3 +108,74 @@ def test_terminal_root_raises_like_reference():
     drv = LockstepMCTS(1, _evaluator(net), 5, 0, 19652, 1.25, rngs=[random.Random(5)])
     with pytest.raises(ValueError):
         drv.predict([env.reset()[1]["state_c"]], lambda i, a, s: env.step([a, s]))
+
+
+class _PerAdapter:
+    """FakeBatchEnv seen through the per-tree `_per` protocol (for the per-node reference search)."""
+
+    def __init__(self, benv):
+        self.benv = benv
+
+    def wrap(self, svec, row, meth):
+        from mcts_q_amd.leafbatch import row_to_obs
+        return {"svec": np.asarray(svec), "obs_norm": row_to_obs(row), "Meth_State": int(meth)}
+
+    def step(self, arg):
+        a, sc = arg
+        nsv, rows, rew, term, trunc, meth = self.benv.step_batch(sc["svec"][None], np.array([a]))
+        nsc = self.wrap(nsv[0], rows[0], meth[0])
+        return nsc["obs_norm"], float(rew[0]), bool(term[0]), bool(trunc[0]), {"state_c": nsc}
+
+
+class _UniformChoice:
+    """random.choice driven by the numpy stream the batched driver draws from (one uniform per expansion)."""
+
+    def __init__(self, seed):
+        self.g = np.random.default_rng(seed)
+
+    def choice(self, seq):
+        return seq[min(int(self.g.random(1)[0] * len(seq)), len(seq) - 1)]
+
+
+def test_batched_environment_mode_equals_reference_search():
+    from mcts_q_amd.synthetic_env import FakeBatchEnv
+    net = _net(2)
+    benv = FakeBatchEnv(horizon=1000)
+    ad = _PerAdapter(benv)
+    drv = LockstepMCTS(1, _evaluator(net), 40, 42, 19652, 1.25, batch_env=benv, seed=9)
+    ref = mcts_ref.RefSearch(_rowwise(net), ad, 40, 42, 19652, 1.25, _UniformChoice(9))
+    st = benv.reset(np.array([5]))
+    for step in range(3):
+        pushed = []
+        a = drv.predict(st, train=True, reuse=[True], push_rows=lambda *x: pushed.append(x))
+        rows, meth = benv.observe(st)
+        a_ref = ref.predict(ad.wrap(st[0], rows[0], meth[0]), "train")
+        assert a[0] == a_ref
+        root, rr = drv.root[0], ref.root
+        got = [(drv.action[c], drv.visits[c], drv.total[c]) for c in drv.child[root][:drv.nchild[root]]]
+        assert got == [(c.action, c.visits, c.total_value) for c in rr.children]
+        assert sum(len(p[1]) for p in pushed) == drv.n - (1 if step == 0 else n_kept)
+        st = benv.step_batch(st, a)[0]
+        drv.advance(a)
+        ref.advance(int(a[0]))
+        n_kept = drv.n
+
+
+def test_batched_mode_many_trees_invariants():
+    from mcts_q_amd.synthetic_env import FakeBatchEnv
+    net = _net(3)
+    benv = FakeBatchEnv(horizon=4)
+    K, iters = 16, 25
+    runs = []
+    for _ in range(2):
+        drv = LockstepMCTS(K, _evaluator(net), iters, 42, 19652, 1.25, batch_env=benv, seed=4)
+        a = drv.predict(benv.reset(np.arange(K)), train=False)
+        runs.append((a.copy(), drv.visits[:drv.n].copy()))
+        assert (drv.visits[drv.root] == iters).all()
+        # every node's visits = 1 (its own evaluation when created or re-selected as terminal) + its children's
+        for n in range(drv.n):
+            ch = drv.child[n][:drv.nchild[n]]
+            term = drv.done[n] or drv.depth[n] >= 42
+            if not term and drv.parent[n] >= 0:
+                assert drv.visits[n] == 1 + drv.visits[ch].sum()
+    assert (runs[0][0] == runs[1][0]).all() and (runs[0][1] == runs[1][1]).all()
