@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--replay", type=int, default=1_000_000, help="replay entries per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-trees", action="store_true")
+    ap.add_argument("--trees", type=int, default=512, help="MCTS trees per rank (BASELINE config 5)")
     ap.add_argument("--backend", default="nccl", help="collective backend (nccl = RCCL; gloo only to rehearse "
                                                      "several ranks on one GPU)")
     args = ap.parse_args()
@@ -271,6 +273,35 @@ def main():
                             "back-propagates its own draws; one flat-gradient all-reduce)",
                  "transitions_per_s": tsteps * Bg / twall, "loss_last": float(L.loss.item())}
 
+    # --- lock-step MCTS in situ (config 5 shape per rank: `trees` trees x 50 iterations, one leaf batch per
+    # iteration, vectorised synthetic environment; search only, weights fixed) -----------------------------
+    trees = None
+    if not args.no_trees:
+        from mcts_q_amd.leafbatch import split_rows
+        from mcts_q_amd.synthetic_env import FakeBatchEnv
+        from mcts_q_amd.treesearch import LockstepMCTS
+
+        def evaluate(rows):
+            o = net(*split_rows(torch.from_numpy(np.ascontiguousarray(rows)).to(dev, non_blocking=True)))
+            return o["vmax"].cpu().numpy(), o["prior"].cpu().numpy()
+
+        benv = FakeBatchEnv()
+        K, iters, tsteps = args.trees, 50, 3
+        drv = LockstepMCTS(K, evaluate, iters, 42, 19652, 1.25, batch_env=benv, seed=rank)
+        st = benv.reset(np.arange(K) + 100000 * rank)
+        a = drv.predict(st, train=False)                      # warm-up search
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(tsteps):
+            st = benv.step_batch(st, a)[0]
+            a = drv.predict(st, train=False)
+        barrier()
+        swall = max_over_ranks(time.perf_counter() - t0)
+        trees = {"metric": "leaf evals/s inside the lock-step tree search (host tree logic + vectorised synthetic "
+                           "environment + one leaf batch per iteration)", "trees_per_gpu": K, "iterations": iters,
+                 "searches": tsteps, "s_per_search_of_all_trees": swall / tsteps,
+                 "value": world * tsteps * K * (iters + 1) / swall, "unit": "leaf evals/s", "scaling": "weak"}
+
     if rank == 0:
         res = {
             "metric": "Q leaf evals/sec (gru/gru/gru, batch 4096 per GPU)",
@@ -286,6 +317,8 @@ def main():
         }
         if train is not None:
             res["train"] = train
+        if trees is not None:
+            res["tree_search"] = trees
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, ref_net, B, args.train_batch)
         print(json.dumps(res), flush=True)
