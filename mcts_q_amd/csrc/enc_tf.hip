@@ -216,8 +216,9 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
 }
 
 // ------------------------------------------------------------------------------------ FFN block
-// hout = LayerNorm2(hin + W2 relu(W1 hin + b1) + b2).  One wave = 64 tokens (4 tiles of 16), one workgroup =
-// 4 waves.  The 2048 hidden units are walked 32 at a time ("pair" of 16-unit tiles); the hidden tile never
+// hout = LayerNorm2(hin + W2 relu(W1 hin + b1) + b2).  One workgroup = 256 tokens, one wave = NT tiles of 16
+// tokens (NT = 1: 16 waves, four per SIMD, so one wave's split / ReLU VALU work overlaps its neighbours' matrix
+// work).  The 2048 hidden units are walked 32 at a time ("pair" of 16-unit tiles); the hidden tile never
 // leaves registers: the D layout of the first product (u^T = W1 . h^T: rows = hidden units, columns =
 // tokens) is exactly the A operand the second product (out = u . W2^T) wants, with the k slots of the
 // 16x16x32 instruction assigned to the units a lane already holds (slot e of lane group q: unit 4q+e of the
@@ -227,40 +228,47 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
 // parameter change (tf_prepare_kernel), u after the ReLU.  The pair's 24 weight fragments (24 KB) are
 // fetched once per workgroup into double-buffered LDS and shared by its four waves.
 constexpr int FFN_FRAGS = 24, FFN_PAIRS = FF / 32;
+#ifndef MCTSQ_FFN_NT
+#define MCTSQ_FFN_NT 1      // token tiles of 16 per wave: 1 -> 16 waves (four per SIMD) per 256-token workgroup; measured 4.01 ms (1), 4.12 (2), 4.73 (4) per 16384-leaf forward
+#endif
 
 #define TF_MM6(ACC, XH, XM, XL, YH, YM, YL)                                              \
     ACC = mfma_bf(XL, YH, ACC); ACC = mfma_bf(XH, YL, ACC); ACC = mfma_bf(XM, YM, ACC);   \
     ACC = mfma_bf(XM, YH, ACC); ACC = mfma_bf(XH, YM, ACC); ACC = mfma_bf(XH, YH, ACC);
 
-__global__ __launch_bounds__(256) void tf_ffn_kernel(TfArgs a, int layer) {
+template <int NT>
+__global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int layer) {
     __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];        // 48 KB
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
     const float* hin = Bf.hmid;
     float* hout = Bf.hout;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
-    const int64_t tok0 = ((int64_t)blockIdx.x * 4 + w) * TOK_PER_WAVE;         // < Tp (grid = Tp / 256)
+    constexpr int NW = 16 / NT, NTHR = 64 * NW, NSTG = (FFN_FRAGS * 64 + NTHR - 1) / NTHR;   // waves, threads, staged b128 per thread
+    const int64_t tok0 = (int64_t)blockIdx.x * TOK_PER_WG + w * (16 * NT);     // < Tp (grid = Tp / 256)
     const u32x4* prep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]);
     // B operand of the first product: h^T, lane (token jl, k group q) holds h[token][32c + 8q .. +7], split
-    u32x4 hh[4][2], hm[4][2], hl[4][2];
+    u32x4 hh[NT][2], hm[NT][2], hl[NT][2];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + 16 * tt + jl) * E + 32 * c + 8 * q);
             split8(p[0], p[1], hh[tt][c], hm[tt][c], hl[tt][c]);
         }
-    f32x4 acc[4][4];
+    f32x4 acc[NT][4];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[tt][c] = (f32x4){0, 0, 0, 0};
 
-    u32x4 stg[6];
+    u32x4 stg[NSTG];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) stg[i] = prep[tid + 256 * i];
+    for (int i = 0; i < NSTG; ++i)
+        if (tid + NTHR * i < FFN_FRAGS * 64) stg[i] = prep[tid + NTHR * i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) wl[0][tid + 256 * i] = stg[i];
+    for (int i = 0; i < NSTG; ++i)
+        if (tid + NTHR * i < FFN_FRAGS * 64) wl[0][tid + NTHR * i] = stg[i];
     const float* b1p = W.l1b + 4 * q;
     float4 b1n0 = *reinterpret_cast<const float4*>(b1p), b1n1 = *reinterpret_cast<const float4*>(b1p + 16);
     __syncthreads();
@@ -269,13 +277,14 @@ __global__ __launch_bounds__(256) void tf_ffn_kernel(TfArgs a, int layer) {
         const float4 b10 = b1n0, b11 = b1n1;
         if (pr + 1 < FFN_PAIRS) {                                   // next pair's fragments and biases in flight
 #pragma unroll
-            for (int i = 0; i < 6; ++i) stg[i] = prep[(int64_t)(pr + 1) * (FFN_FRAGS * 64) + tid + 256 * i];
+            for (int i = 0; i < NSTG; ++i)
+                if (tid + NTHR * i < FFN_FRAGS * 64) stg[i] = prep[(int64_t)(pr + 1) * (FFN_FRAGS * 64) + tid + NTHR * i];
             b1n0 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32);
             b1n1 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32 + 16);
         }
         const u32x4* wf = &wl[buf][lane];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < NT; ++tt) {
             // ---- u^T = W1 . h^T for the pair's two unit tiles (bias of hidden unit 4q + r preloaded) ----
             f32x4 ua = {b10.x, b10.y, b10.z, b10.w}, ub = {b11.x, b11.y, b11.z, b11.w};
 #pragma unroll
@@ -301,14 +310,15 @@ __global__ __launch_bounds__(256) void tf_ffn_kernel(TfArgs a, int layer) {
         }
         if (pr + 1 < FFN_PAIRS) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) wl[buf ^ 1][tid + 256 * i] = stg[i];
+            for (int i = 0; i < NSTG; ++i)
+                if (tid + NTHR * i < FFN_FRAGS * 64) wl[buf ^ 1][tid + NTHR * i] = stg[i];
         }
         __syncthreads();
     }
     if (tok0 >= a.T) return;
     // ---- + b2 + residual, LayerNorm2 -------------------------------------------------------------
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
+    for (int tt = 0; tt < NT; ++tt) {
         float x[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -398,7 +408,7 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
     const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / TOK_PER_WG);
     for (int l = 0; l < 2; ++l) {
         hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(256), 0, st, a, l);
-        hipLaunchKernelGGL(tf_ffn_kernel, dim3(ffn_grid), dim3(256), 0, st, a, l);
+        hipLaunchKernelGGL(tf_ffn_kernel<MCTSQ_FFN_NT>, dim3(ffn_grid), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st, a, l);
     }
     hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
