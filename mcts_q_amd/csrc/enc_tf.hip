@@ -65,7 +65,7 @@ __device__ __forceinline__ void ln_rows(float x[4][4], const float* lnw, const f
 // head) softmax(q k^T / 4) v -> out_proj -> + h -> LayerNorm1.
 constexpr int AHLD = 68, QLD = 196, AROWS = 128;
 
-__global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
+__global__ __launch_bounds__(512) void tf_attn_kernel(TfArgs a, int layer) {
     __shared__ __attribute__((aligned(16))) float hs[AROWS * AHLD];
     __shared__ __attribute__((aligned(16))) float qkv[AROWS * QLD];
     const TfLayerW& W = a.layer[layer];
@@ -79,49 +79,54 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
     const int rows = ns * S;
     const int64_t tok0 = sample0 * S;
 
-    for (int idx = tid; idx < AROWS * 16; idx += 256) {
+    for (int idx = tid; idx < AROWS * 16; idx += 512) {
         const int r = idx >> 4, c4 = idx & 15;
         float4 v = make_float4(0, 0, 0, 0);
         if (r < rows) v = reinterpret_cast<const float4*>(hin + (tok0 + r) * E)[c4];
         *reinterpret_cast<float4*>(&hs[r * AHLD + 4 * c4]) = v;
     }
     __syncthreads();
-    // ---- in_proj: [128 x 64] . W_in^T [64 x 192]; wave w owns row tiles 2w, 2w+1 --------------
+    // ---- in_proj: [128 x 64] . W_in^T [64 x 192]; wave w (of 8) owns row tile w ---------------------
     {
-        float af[2][16];
+        float af[16];
+        {
+            const float4* p = reinterpret_cast<const float4*>(&hs[(16 * w + jl) * AHLD + 16 * q]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const float4* p = reinterpret_cast<const float4*>(&hs[(32 * w + 16 * mt + jl) * AHLD + 16 * q]);
+            for (int c = 0; c < 4; ++c) { const float4 v = p[c]; af[4 * c] = v.x; af[4 * c + 1] = v.y; af[4 * c + 2] = v.z; af[4 * c + 3] = v.w; }
+        }
+        float4 wn[4];
+        {
+            const float4* p = reinterpret_cast<const float4*>(W.inw + (int64_t)jl * E + 16 * q);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float4 v = p[c]; af[mt][4 * c] = v.x; af[mt][4 * c + 1] = v.y; af[mt][4 * c + 2] = v.z; af[mt][4 * c + 3] = v.w; }
+            for (int c = 0; c < 4; ++c) wn[c] = p[c];
         }
         for (int nt = 0; nt < 12; ++nt) {
-            const float4* p = reinterpret_cast<const float4*>(W.inw + (int64_t)(16 * nt + jl) * E + 16 * q);
             float bf[16];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float4 v = p[c]; bf[4 * c] = v.x; bf[4 * c + 1] = v.y; bf[4 * c + 2] = v.z; bf[4 * c + 3] = v.w; }
+            for (int c = 0; c < 4; ++c) { const float4 v = wn[c]; bf[4 * c] = v.x; bf[4 * c + 1] = v.y; bf[4 * c + 2] = v.z; bf[4 * c + 3] = v.w; }
+            if (nt + 1 < 12) {                                      // next tile's weight fragment in flight
+                const float4* p = reinterpret_cast<const float4*>(W.inw + (int64_t)(16 * (nt + 1) + jl) * E + 16 * q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wn[c] = p[c];
+            }
             f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc0 = mfma16(af[0][e], bf[e], acc0); acc1 = mfma16(af[1][e], bf[e], acc1); }
+            for (int e = 0; e < 16; e += 2) { acc0 = mfma16(af[e], bf[e], acc0); acc1 = mfma16(af[e + 1], bf[e + 1], acc1); }
             const float bias = W.inb[16 * nt + jl];
             const float sc = nt < 4 ? 0.25f : 1.0f;                  // q / sqrt(head_dim)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v0 = (acc0[r] + bias) * sc, v1 = (acc1[r] + bias) * sc;
-                const int r0 = 32 * w + 4 * q + r, r1 = r0 + 16;
+                const float v0 = ((acc0[r] + acc1[r]) + bias) * sc;
+                const int r0 = 16 * w + 4 * q + r;
                 qkv[r0 * QLD + 16 * nt + jl] = v0;
-                qkv[r1 * QLD + 16 * nt + jl] = v1;
-                if (Bf.qkv) {
-                    if (r0 < rows) Bf.qkv[(tok0 + r0) * G3 + 16 * nt + jl] = v0;
-                    if (r1 < rows) Bf.qkv[(tok0 + r1) * G3 + 16 * nt + jl] = v1;
-                }
+                if (Bf.qkv && r0 < rows) Bf.qkv[(tok0 + r0) * G3 + 16 * nt + jl] = v0;
             }
         }
     }
     __syncthreads();
     // ---- attention: one wave per (sample, head) ------------------------------------------------
     const int nt16 = (S + 15) >> 4;                                 // key / query tiles per sample (1 or 2)
-    for (int p = w; p < ns * 4; p += 4) {
+    for (int p = w; p < ns * 4; p += 8) {
         const int si = p >> 2, hh = p & 3, rb = si * S;
         for (int qt = 0; qt < nt16; ++qt) {
             const int qrow = min(rb + 16 * qt + jl, AROWS - 1);
@@ -177,9 +182,8 @@ __global__ __launch_bounds__(256) void tf_attn_kernel(TfArgs a, int layer) {
     }
     __syncthreads();
     // ---- out_proj + residual + LayerNorm1 --------------------------------------------------------
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int rbase = 32 * w + 16 * mt;
+    {
+        const int rbase = 16 * w;
         const float4* p = reinterpret_cast<const float4*>(&qkv[(rbase + jl) * QLD + 16 * q]);
         float af[16];
 #pragma unroll
@@ -407,7 +411,7 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp * E / 256)), dim3(256), 0, st, a);
     const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / TOK_PER_WG);
     for (int l = 0; l < 2; ++l) {
-        hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(256), 0, st, a, l);
+        hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(512), 0, st, a, l);
         hipLaunchKernelGGL(tf_ffn_kernel<MCTSQ_FFN_NT>, dim3(ffn_grid), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st, a, l);
     }
     hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);
