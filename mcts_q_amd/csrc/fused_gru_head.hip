@@ -72,10 +72,9 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     STAMP(0);
     GruWave<SAVE> g;
     g.bind(lane, wq);
-    if ((MCTSQ_EXP & 8) && grp == 1) __syncthreads();  // ablation: long window only
-    else run_window<SAVE>(g, ga.slot[sa], G, L.feats, gtid, row0, ga.B, ga.Bp, true);
+    run_window<SAVE>(g, ga.slot[sa], G, L.feats, gtid, row0, ga.B, ga.Bp, true);
     STAMP(1);
-    if (grp == 1 && !(MCTSQ_EXP & 24)) {
+    if (grp == 1) {
         g.sync(G);                                    // every wave is done with the first window's LDS
         run_window<SAVE>(g, ga.slot[sb], G, L.feats, gtid, row0, ga.B, ga.Bp, false);
     }

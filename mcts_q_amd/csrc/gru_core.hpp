@@ -21,10 +21,6 @@
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
-#ifndef MCTSQ_EXP
-#define MCTSQ_EXP 0      // timing-ablation bit mask (tools/exp_run.sh); 0 in the product build
-#endif
-
 namespace mctsq {
 
 constexpr int HLD = 72;     // LDS row stride of an h plane (bf16 elements): 144 B keeps b128 reads conflict-free
@@ -94,7 +90,7 @@ struct GruWave {
 
     __device__ __forceinline__ void sync(GruLds& L) {
         nsync += 4;
-        if (!(MCTSQ_EXP & 4)) group_sync(&L.arrivals, nsync, lane);
+        group_sync(&L.arrivals, nsync, lane);
     }
 
     // cooperative over the group's 256 lanes (gtid): xs[i][t*FP + f] (zero padded), h planes of buffer 0 = 0.
@@ -246,35 +242,29 @@ struct GruWave {
         ACC0 = mfma_bf(am[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(am[C], whi[G1][C], ACC1);    \
         ACC0 = mfma_bf(ah[C], wmid[G0][C], ACC0); ACC1 = mfma_bf(ah[C], wmid[G1][C], ACC1);   \
         ACC0 = mfma_bf(ah[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(ah[C], whi[G1][C], ACC1);
-        if (!(MCTSQ_EXP & 32)) {
         T6(accr, accz, 0, 1, 0)
         T6(accr, accz, 0, 1, 1)
-        }
-        if (!(MCTSQ_EXP & 1)) {                               // pooling, two steps behind (see above)
-            publish(L, nxt);                                  // partial scores of h_{t-1} (still in h)
-            attend(s, sp, hp, t >= 2, t >= 2 ? t - 2 : 0, row0, Bp);
-        }
+        publish(L, nxt);                                      // pooling, two steps behind: scores of h_{t-1}
+        attend(s, sp, hp, t >= 2, t >= 2 ? t - 2 : 0, row0, Bp);
 #undef T6
         // n gate: K chunk 0 into accn, chunk 1 into accm (two independent chains)
-        if (!(MCTSQ_EXP & 32)) {
         accn = mfma_bf(al[0], whi[2][0], accn);  accm = mfma_bf(al[1], whi[2][1], accm);
         accn = mfma_bf(ah[0], wlo[2][0], accn);  accm = mfma_bf(ah[1], wlo[2][1], accm);
         accn = mfma_bf(am[0], wmid[2][0], accn); accm = mfma_bf(am[1], wmid[2][1], accm);
         accn = mfma_bf(am[0], whi[2][0], accn);  accm = mfma_bf(am[1], whi[2][1], accm);
         accn = mfma_bf(ah[0], wmid[2][0], accn); accm = mfma_bf(ah[1], wmid[2][1], accm);
         accn = mfma_bf(ah[0], whi[2][0], accn);  accm = mfma_bf(ah[1], whi[2][1], accm);
-        }
         float rg[4], zg[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            rg[r] = (MCTSQ_EXP & 2) ? accr[r] + br : sigmoid_fast(accr[r] + br);
-            zg[r] = (MCTSQ_EXP & 2) ? accz[r] + bz : sigmoid_fast(accz[r] + bz);
+            rg[r] = sigmoid_fast(accr[r] + br);
+            zg[r] = sigmoid_fast(accz[r] + bz);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
             const float hn = (accn[r] + accm[r]) + bhn;
-            const float ng = (MCTSQ_EXP & 2) ? (acci[r] + bin) + rg[r] * hn : tanh_fast((acci[r] + bin) + rg[r] * hn);
+            const float ng = tanh_fast((acci[r] + bin) + rg[r] * hn);
             const float hnew = ng + zg[r] * (h[r] - ng);
             unsigned u0, u1, u2;
             split3(hnew, u0, u1, u2);
