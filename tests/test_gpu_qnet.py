@@ -113,3 +113,27 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libmctsq_hip.so")
     with pytest.raises(L.MctsqError):
         L._Lib().mctsq_abi_version()
+
+
+@pytest.mark.parametrize("name,B,base", [("transformer_transformer_gru_per_relu", 16384, 300),
+                                         ("gru_gru_gru_per_relu", 65536, 4096)])
+def test_full_size_batch_is_position_independent(name, B, base):
+    """BASELINE config 4 (16384 transformer leaves) and a 65536-leaf GRU batch, through a size-independent
+    property: a leaf's outputs do not depend on where it sits in the batch or on what surrounds it.  The batch is
+    `base` distinct leaves (a size the oracle checks directly above) repeated with a rotation; every copy must
+    give bit-identical Q, value, greedy action and prior."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, f"qnet_{name}.npz"))
+    g = torch.Generator().manual_seed(7)
+    small = [torch.rand(base, 25, 1, generator=g), torch.rand(base, 10, 6, generator=g), torch.rand(base, 3, 2, generator=g)]
+    idx = (torch.arange(B) * 7 + 3) % base                      # position i holds leaf idx[i]
+    big = [t[idx].contiguous().cuda() for t in small]
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    ref = net(*[t.cuda() for t in small])
+    ref = {k: v.cpu() for k, v in ref.items()}
+    out = net(*big)
+    for k in ("q", "vmax", "argmax", "prior"):
+        assert torch.equal(out[k].cpu(), ref[k][idx]), k
+    ref64 = qnet_numpy.q_forward(sd, cfg, *[t.numpy() for t in small], np.float64)
+    assert np.abs(ref["q"].numpy() - ref64).max() <= 1e-5 * np.abs(ref64).max()
