@@ -19,7 +19,6 @@ __global__ __launch_bounds__(256) void gru_enc_fwd_kernel(GruFwdArgs args) {
     __syncthreads();
     if (SAVE) g.save_window(s, L, threadIdx.x, row0, args.Bp);
     g.run(s, L, row0, args.Bp);
-    g.attend_flush(s, L, row0, args.Bp);
     g.fin0(L);
     g.sync(L);
     g.fin1(L);

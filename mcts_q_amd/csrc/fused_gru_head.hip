@@ -44,7 +44,6 @@ __device__ __forceinline__ void run_window(GruWave<SAVE>& g, const GruSlot& s, G
     if (SAVE) g.save_window(s, G, gtid, row0, Bp);
     g.run(s, G, row0, Bp);
     WSTAMP(3);
-    g.attend_flush(s, G, row0, Bp);
     WSTAMP(4);
     g.fin0(G);
     g.sync(G);
@@ -58,7 +57,11 @@ template <bool SAVE>
 __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadArgs ha) {
     __shared__ __attribute__((aligned(16))) FusedLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MCTSQ_EXP_SWAP
+    const int grp = (wave >> 2) ^ 1, wq = wave & 3, gtid = tid & 255;
+#else
     const int grp = wave >> 2, wq = wave & 3, gtid = tid & 255;
+#endif
     const int jl = lane & 15, q = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * TILE;
     GruLds& G = L.g[grp];
@@ -69,6 +72,9 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     const int sa = grp == 0 ? big : (big == 0 ? 1 : 0);
     const int sb = big == 2 ? 1 : 2;
 
+#ifdef MCTSQ_EXP_PRIO
+    if (grp == 1) __builtin_amdgcn_s_setprio(MCTSQ_EXP_PRIO); else __builtin_amdgcn_s_setprio(0);
+#endif
     STAMP(0);
     GruWave<SAVE> g;
     g.bind(lane, wq);

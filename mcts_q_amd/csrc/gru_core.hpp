@@ -50,8 +50,11 @@ template <bool SAVE>
 struct GruWave {
     u32x4 whi[3][2], wmid[3][2], wlo[3][2];   // W_hh[g*64 + j][32c + 8q .. +7], gate g, K chunk c, split
     float wir[2], wiz[2], win[2];   // W_ih[g*64 + j][q (+4)], zero padded
-    float br, bz, bin, bhn, awj, ab;
-    float h[4], hp[4], att[4], mrun[4], lrun[4];
+    f32x4 brv, bzv, binv, bhnv;     // gate biases replicated over the 4 accumulator rows: the accumulators START from them
+    float awj, abl;                 // score weight of unit j (log2 units); the score bias rides on one lane's product
+    float hh[2][4];                 // hh[t & 1] = h_t (this wave's 16 units, rows 4q..4q+3)
+    float att[4], mrun[4], lrun[4];
+    bool bounded;                   // scores provably inside +-60 (log2 units): softmax without the running max
     float pooled[4], mean[4], rstd[4];
     int lane, wq, jl, q, j, FP;
     unsigned nsync;
@@ -81,11 +84,32 @@ struct GruWave {
             wiz[ks] = ok ? s.wih[(int64_t)(1 * E + j) * F + k] : 0.0f;
             win[ks] = ok ? s.wih[(int64_t)(2 * E + j) * F + k] : 0.0f;
         }
-        br = s.bih[j] + s.bhh[j]; bz = s.bih[E + j] + s.bhh[E + j];
-        bin = s.bih[2 * E + j]; bhn = s.bhh[2 * E + j];
-        awj = s.aw[j] * LOG2E; ab = s.ab[0] * LOG2E;          // softmax evaluated in base 2
+        {
+            const float br = s.bih[j] + s.bhh[j], bz = s.bih[E + j] + s.bhh[E + j];
+            const float bin = s.bih[2 * E + j], bhn = s.bhh[2 * E + j];
+            brv = (f32x4){br, br, br, br}; bzv = (f32x4){bz, bz, bz, bz};
+            binv = (f32x4){bin, bin, bin, bin}; bhnv = (f32x4){bhn, bhn, bhn, bhn};
+        }
+        const float ab = s.ab[0] * LOG2E;                     // softmax evaluated in base 2
+        awj = s.aw[j] * LOG2E;
+        abl = (wq == 0 && jl == 0) ? ab : 0.0f;
+        // |h| <= 1, so |score| <= sum_j |aw_j| + |ab|: when that bound is small exp2(score) can neither
+        // overflow nor vanish and the softmax over time needs no running maximum (attend<true>).
+        // Every lane of every wave evaluates the same expression, so the four waves agree.
+        float bound = fabsf(s.aw[jl]) + fabsf(s.aw[16 + jl]) + fabsf(s.aw[32 + jl]) + fabsf(s.aw[48 + jl]);
+        bound = (row16_sum(bound) + fabsf(s.ab[0])) * LOG2E;
+        bounded = __builtin_amdgcn_readfirstlane(bound < 60.0f ? 1 : 0) != 0;
+        // The pooling trails the recurrence by two steps, so the first two folds of a window see no step
+        // yet ("dead" folds).  Bounded mode lets them run unconditionally: h_{-1} = h_{-2} = 0 adds nothing
+        // to att, both dead scores are exactly ab (stage() seeds the slot the first one reads), and lrun
+        // starts at minus their weight: -2p + p + p == 0 exactly.
+        const float pdead = fast_exp2(ab);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = 0.0f; hp[r] = 0.0f; att[r] = 0.0f; lrun[r] = 0.0f; mrun[r] = -1e30f; }
+        for (int r = 0; r < 4; ++r) {
+            hh[0][r] = 0.0f; hh[1][r] = 0.0f; att[r] = 0.0f;
+            lrun[r] = bounded ? -2.0f * pdead : 0.0f;
+            mrun[r] = bounded ? 0.0f : -1e30f;
+        }
     }
 
     __device__ __forceinline__ void sync(GruLds& L) {
@@ -128,6 +152,7 @@ struct GruWave {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             for (int idx = gtid; idx < TILE * HLD / 2; idx += 256) reinterpret_cast<unsigned*>(L.hb[pl][0])[idx] = 0u;
+        if (gtid < 64) L.spart[0][gtid >> 4][gtid & 15] = gtid < 16 ? s.ab[0] * LOG2E : 0.0f;   // score of h_{-2}: ab
         if (first && gtid == 0) L.arrivals = 0;
         if (SAVE)
             for (int idx = gtid; idx < TILE * E; idx += 256) s.sv_h[row0 * E + idx] = 0.0f;   // h_{-1}
@@ -148,10 +173,10 @@ struct GruWave {
     // visible behind sync t+1).  spart is indexed by step parity: step t writes parity (t-1)&1 and
     // reads parity t&1; a wave cannot run more than one sync ahead, and its reads are complete
     // before it arrives (the release fence drains lgkmcnt), so the two never collide.
-    __device__ __forceinline__ void publish(GruLds& L, int par) {
+    __device__ __forceinline__ void publish(GruLds& L, const float (&hv)[4], int par) {
         float4 ps;
-        ps.x = row16_sum(awj * h[0]); ps.y = row16_sum(awj * h[1]);
-        ps.z = row16_sum(awj * h[2]); ps.w = row16_sum(awj * h[3]);
+        ps.x = row16_sum(fmaf(awj, hv[0], abl)); ps.y = row16_sum(fmaf(awj, hv[1], abl));
+        ps.z = row16_sum(fmaf(awj, hv[2], abl)); ps.w = row16_sum(fmaf(awj, hv[3], abl));
         // one lane per row group stores; the others write their (identical) sums to a dump slot of
         // their own, which keeps the instruction stream branch-free for the interleaving below
         float* dst = jl == 0 ? &L.spart[par][wq][4 * q] : &L.dump[wq][lane * 4];
@@ -167,51 +192,66 @@ struct GruWave {
         lrun[r] = lrun[r] * c_old + c_new;
         mrun[r] = up ? sc : mrun[r];
     }
-    // fold hv (= h_t of this wave's units, whose score parts are in sp) into the running sums
+    // fold hv (= h_t of this wave's units, whose score parts are in sp) into the running sums.
+    // BND: plain sums of exp2(score) (mrun stays 0); otherwise the online form with a running maximum.
+    template <bool BND>
     __device__ __forceinline__ void attend(const GruSlot& s, const float4 (&sp)[4], const float (&hv)[4], bool live,
                                            int t, int64_t row0, int64_t Bp) {
         const float p[4][4] = {{sp[0].x, sp[0].y, sp[0].z, sp[0].w}, {sp[1].x, sp[1].y, sp[1].z, sp[1].w},
                                {sp[2].x, sp[2].y, sp[2].z, sp[2].w}, {sp[3].x, sp[3].y, sp[3].z, sp[3].w}};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float sc = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) + ab;
+            float sc = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
             if (SAVE && live && wq == 0 && jl == 0) s.sv_score[(int64_t)t * Bp + row0 + 4 * q + r] = sc;   // log2 units
-            sc = live ? sc : -INFINITY;
-            fold(sc, fast_exp2(-fabsf(sc - mrun[r])), hv[r], r);
+            if (BND) {
+                const float e = fast_exp2(sc);
+                att[r] = fmaf(e, hv[r], att[r]);
+                lrun[r] += e;
+            } else {
+                sc = live ? sc : -INFINITY;
+                fold(sc, fast_exp2(-fabsf(sc - mrun[r])), hv[r], r);
+            }
         }
     }
     __device__ __forceinline__ void load_spart(GruLds& L, int par, float4 (&sp)[4]) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) sp[w] = *reinterpret_cast<const float4*>(&L.spart[par][w][4 * q]);
     }
-    // the whole recurrence: S steps, each followed by the group sync
-    __device__ __forceinline__ void run(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
-        // unrolled by two: the double-buffer parity becomes a constant and h / hp swap roles
-        // without register copies
-        if (FP == 8) {
-#pragma unroll 2
-            for (int t = 0; t < s.S; ++t) { step<true>(s, L, t, row0, Bp); sync(L); }
-        } else {
-#pragma unroll 2
-            for (int t = 0; t < s.S; ++t) { step<false>(s, L, t, row0, Bp); sync(L); }
+    // the whole recurrence: S steps, each followed by the group sync.  Unrolled by two by hand: the
+    // double-buffer parity is a template constant and h_t / h_{t-1} swap roles without register copies
+    template <bool FP8, bool BND>
+    __device__ __forceinline__ void run_(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
+        int t = 0;
+        for (; t + 1 < s.S; t += 2) {
+            step<FP8, BND, 0>(s, L, t, row0, Bp); sync(L);
+            step<FP8, BND, 1>(s, L, t + 1, row0, Bp); sync(L);
         }
+        if (t < s.S) { step<FP8, BND, 0>(s, L, t, row0, Bp); sync(L); }
+        // h_{S-1} = hh[(S-1) & 1], h_{S-2} = hh[S & 1]: two more folds, one sync between them
+        if (s.S & 1) flush_<BND, 0>(s, L, row0, Bp);
+        else flush_<BND, 1>(s, L, row0, Bp);
     }
-    // after the loop: h = h_{S-1}, hp = h_{S-2}; two more folds, one sync between them
-    __device__ __forceinline__ void attend_flush(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
+    __device__ __forceinline__ void run(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
+        if (FP == 8) { if (bounded) run_<true, true>(s, L, row0, Bp); else run_<true, false>(s, L, row0, Bp); }
+        else { if (bounded) run_<false, true>(s, L, row0, Bp); else run_<false, false>(s, L, row0, Bp); }
+    }
+    template <bool BND, int LAST>                             // LAST = (S - 1) & 1
+    __device__ __forceinline__ void flush_(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
         const int S = s.S;
         float4 sp[4];
-        publish(L, (S - 1) & 1);
-        load_spart(L, S & 1, sp);
-        attend(s, sp, hp, S >= 2, S - 2, row0, Bp);
+        publish(L, hh[LAST], LAST);
+        load_spart(L, LAST ^ 1, sp);
+        attend<BND>(s, sp, hh[LAST ^ 1], S >= 2, S - 2, row0, Bp);
         sync(L);
-        load_spart(L, (S - 1) & 1, sp);
-        attend(s, sp, h, true, S - 1, row0, Bp);
+        load_spart(L, LAST, sp);
+        attend<BND>(s, sp, hh[LAST], true, S - 1, row0, Bp);
     }
 
-    // one recurrence step; the caller follows with sync()
-    template <bool FP8>
+    // one recurrence step t (PAR = t & 1); the caller follows with sync().  On entry hh[PAR ^ 1] = h_{t-1},
+    // hh[PAR] = h_{t-2}; on exit hh[PAR] = h_t.
+    template <bool FP8, bool BND, int PAR>
     __device__ __forceinline__ void step(const GruSlot& s, GruLds& L, int t, int64_t row0, int64_t Bp) {
-        const int cur = t & 1, nxt = cur ^ 1;
+        constexpr int cur = PAR, nxt = PAR ^ 1;
         // A fragments of h_{t-1}: plane pl, K chunk c -> 8 bf16 of row lane&15 at k = 32c + 8q
         u32x4 ah[2], am[2], al[2];
         {
@@ -228,9 +268,8 @@ struct GruWave {
         const float x1 = FP8 ? xa[4] : 0.0f;
         float4 sp[4];
         load_spart(L, cur, sp);
-        f32x4 accr = {0, 0, 0, 0}, accz = {0, 0, 0, 0}, accn = {0, 0, 0, 0}, accm = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
-        // input projection, exact fp32
-        accr = mfma16(x0, wir[0], accr); accz = mfma16(x0, wiz[0], accz); acci = mfma16(x0, win[0], acci);
+        // input projection, exact fp32, on top of the biases
+        f32x4 accr = mfma16(x0, wir[0], brv), accz = mfma16(x0, wiz[0], bzv), acci = mfma16(x0, win[0], binv);
         if (FP8) {
             accr = mfma16(x1, wir[1], accr); accz = mfma16(x1, wiz[1], accz); acci = mfma16(x1, win[1], acci);
         }
@@ -244,11 +283,11 @@ struct GruWave {
         ACC0 = mfma_bf(ah[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(ah[C], whi[G1][C], ACC1);
         T6(accr, accz, 0, 1, 0)
         T6(accr, accz, 0, 1, 1)
-        publish(L, nxt);                                      // pooling, two steps behind: scores of h_{t-1}
-        attend(s, sp, hp, t >= 2, t >= 2 ? t - 2 : 0, row0, Bp);
 #undef T6
-        // n gate: K chunk 0 into accn, chunk 1 into accm (two independent chains)
-        accn = mfma_bf(al[0], whi[2][0], accn);  accm = mfma_bf(al[1], whi[2][1], accm);
+        publish(L, hh[nxt], nxt);                             // pooling, two steps behind: scores of h_{t-1}
+        attend<BND>(s, sp, hh[cur], t >= 2, t >= 2 ? t - 2 : 0, row0, Bp);   // ... and the fold of h_{t-2}
+        // n gate: K chunk 0 into accn (on top of b_hn), chunk 1 into accm (two independent chains)
+        f32x4 accn = mfma_bf(al[0], whi[2][0], bhnv), accm = mfma_bf(al[1], whi[2][1], (f32x4){0, 0, 0, 0});
         accn = mfma_bf(ah[0], wlo[2][0], accn);  accm = mfma_bf(ah[1], wlo[2][1], accm);
         accn = mfma_bf(am[0], wmid[2][0], accn); accm = mfma_bf(am[1], wmid[2][1], accm);
         accn = mfma_bf(am[0], whi[2][0], accn);  accm = mfma_bf(am[1], whi[2][1], accm);
@@ -257,15 +296,15 @@ struct GruWave {
         float rg[4], zg[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            rg[r] = sigmoid_fast(accr[r] + br);
-            zg[r] = sigmoid_fast(accz[r] + bz);
+            rg[r] = sigmoid_fast(accr[r]);
+            zg[r] = sigmoid_fast(accz[r]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            const float hn = (accn[r] + accm[r]) + bhn;
-            const float ng = tanh_fast((acci[r] + bin) + rg[r] * hn);
-            const float hnew = ng + zg[r] * (h[r] - ng);
+            const float hn = accn[r] + accm[r];
+            const float ng = tanh_fast(acci[r] + rg[r] * hn);
+            const float hnew = ng + zg[r] * (hh[nxt][r] - ng);
             unsigned u0, u1, u2;
             split3(hnew, u0, u1, u2);
             L.hb[0][nxt][i * HLD + j] = (unsigned short)(u0 >> 16);
@@ -275,8 +314,7 @@ struct GruWave {
                 const int64_t o = ((int64_t)t * Bp + row0 + i) * E + j;
                 s.sv_r[o] = rg[r]; s.sv_z[o] = zg[r]; s.sv_n[o] = ng; s.sv_hn[o] = hn; s.sv_h[o + Bp * E] = hnew;
             }
-            hp[r] = h[r];
-            h[r] = hnew;
+            hh[cur][r] = hnew;
         }
     }
 

@@ -191,16 +191,24 @@ def test_clip_adam_polyak_matches_torch():
 
 
 @pytest.mark.parametrize("combo", ["gru/gru/gru", "conv/conv/mlp", "gru/conv/gru", "transformer/transformer/gru",
-                                   "transformer/gru/mlp"])
+                                   "transformer/gru/mlp", "gru/gru/gru+sharp"])
 @pytest.mark.parametrize("B", [5, 1024])
 def test_gradient_matches_torch_autograd_batched(B, combo):
-    """Ragged and BASELINE config-3 batch sizes vs autograd of the torch oracle, real target path."""
+    """Ragged and BASELINE config-3 batch sizes vs autograd of the torch oracle, real target path.
+    "gru/gru/gru+sharp": attention score weights scaled up so the GRU kernels take the running-max
+    softmax path (gru_core.hpp) in the training forward as well."""
     from mcts_q_amd import NetSpec
     from mcts_q_amd.learner import DeviceLearner
-    pe, pr, ga = combo.split("/")
+    sharp = combo.endswith("+sharp")
+    pe, pr, ga = combo.replace("+sharp", "").split("/")
     cfg = dict(price=pe, process=pr, gas=ga, act="relu", flavor="per")
     torch.manual_seed(7)
     net, tgt = torch_ref.RefQNet(cfg), torch_ref.RefQNet(cfg)
+    if sharp:
+        with torch.no_grad():
+            for m in (net, tgt):
+                m.price_encoder.attention_weights.weight *= 60.0
+                m.process_encoder.attention_weights.weight *= 60.0
     spec = NetSpec.from_cfg(cfg)
     L = DeviceLearner(spec).load_state_dict({k: v.detach().numpy() for k, v in net.state_dict().items()},
                                             {k: v.detach().numpy() for k, v in tgt.state_dict().items()})

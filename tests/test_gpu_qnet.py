@@ -137,3 +137,26 @@ def test_full_size_batch_is_position_independent(name, B, base):
         assert torch.equal(out[k].cpu(), ref[k][idx]), k
     ref64 = qnet_numpy.q_forward(sd, cfg, *[t.numpy() for t in small], np.float64)
     assert np.abs(ref["q"].numpy() - ref64).max() <= 1e-5 * np.abs(ref64).max()
+
+
+@pytest.mark.parametrize("B", [3, 257])
+def test_gru_sharp_attention_uses_running_max(B):
+    """The GRU encoders evaluate the softmax over time without a running maximum when the score bound
+    sum|aw| + |ab| is small (every trained or freshly initialised network here), and fall back to the
+    online form otherwise.  Scaling the score weights of two encoders by 60 forces the fallback (bound ~250 in
+    log2 units; the third encoder stays on the bounded path), near one-hot attention included."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, "qnet_gru_gru_gru_per_relu.npz"))
+    sd = {k: v.copy() for k, v in sd.items()}
+    for enc in ("price_encoder", "process_encoder"):
+        sd[enc + ".attention_weights.weight"] *= 60.0
+        sd[enc + ".attention_weights.bias"] += 3.0
+    g = torch.Generator().manual_seed(100 + B)
+    price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
+        torch.rand(B, 3, 2, generator=g)
+    ref64 = qnet_numpy.q_forward(sd, cfg, price.numpy(), process.numpy(), gas.numpy(), np.float64)
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    q = net(price.cuda(), process.cuda(), gas.cuda())["q"].cpu().numpy()
+    assert np.isfinite(q).all()
+    assert np.abs(q - ref64).max() <= 1e-5 * np.abs(ref64).max()

@@ -23,7 +23,7 @@ d = np.diff(st, axis=0)
 for w in range(8):
     print(w, d[:, w], "total", st[3, w] - st[0, w])
 it = out[64:64 + 32]
-for name, base in (("group0 window", 0), ("group1 first", 8), ("group1 second", 24)):
+for name, base in (("waves0-3 first", 0), ("waves4-7 first", 8), ("waves0-3 second", 16), ("waves4-7 second", 24)):
     v = it[base:base + 6]
     print(name, "start@%d" % (v[0] - st[0].min()), "init+stage, sync, loop, flush, LN:", np.diff(v))
 print("kernel span (all waves):", st[3].max() - st[0].min())
