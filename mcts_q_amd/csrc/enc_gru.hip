@@ -14,16 +14,16 @@ __global__ __launch_bounds__(256) void gru_enc_fwd_kernel(GruFwdArgs args) {
     __shared__ __attribute__((aligned(16))) GruLds L;
     GruWave<SAVE> g;
     g.bind(threadIdx.x & 63, threadIdx.x >> 6);
-    g.init(s);
-    g.stage(s, L, threadIdx.x, row0, args.B, args.Bp);
+    g.stage_issue(s, threadIdx.x, row0, args.B);
+    g.init_weights(s);
+    g.init_state();
+    g.stage_commit(s, L, threadIdx.x, row0, args.B, args.Bp);
     __syncthreads();
     if (SAVE) g.save_window(s, L, threadIdx.x, row0, args.Bp);
     g.run(s, L, row0, args.Bp);
     g.fin0(L);
     g.sync(L);
-    g.fin1(L);
-    g.sync(L);
-    g.fin2(s, L, args.feats + row0 * FEAT + s.out_col, FEAT, row0);
+    g.fin2(s, L, args.feats + row0 * FEAT + s.out_col, FEAT, row0, g.lnwj, g.lnbj);
 }
 
 // one thread per (slot, wave, gate, K chunk, lane): 8 consecutive weights -> 3 x 8 bf16

@@ -13,14 +13,17 @@ namespace mctsq {
 constexpr int FLD = FEAT + 4;    // feature tile row stride in LDS
 constexpr int ALD1 = 128 + 4;    // hidden activation row stride
 
+// Diagnostic build (-DMCTSQ_STAMPS): s_memtime stamps of the LAST workgroup, kept in LDS while the kernel runs
+// (a global store per stamp queues behind the head-weight loads and distorts what it measures) and
+// copied out at the end; read by tools/stamps.py.
 #ifdef MCTSQ_STAMPS
 __device__ long long g_stamps[4 * 64];
 __device__ long long g_iter[192];
-#define STAMP(k) do { if (blockIdx.x == 0 && lane == 0) g_stamps[(k) * 16 + wave] = __builtin_amdgcn_s_memtime(); } while (0)
-#define WSTAMP(k) do { if (blockIdx.x == 0 && gtid == 0) g_iter[(first ? 0 : 16) + ((gtid != (int)threadIdx.x) ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(k) do { if (blockIdx.x == gridDim.x - 1 && lane == 0) L.st[(k) * 16 + wave] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WSTAMP(win, k) do { if (blockIdx.x == gridDim.x - 1 && gtid == 0) L.wst[(win) * 16 + ((gtid != (int)threadIdx.x) ? 8 : 0) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(k) do {} while (0)
-#define WSTAMP(k) do {} while (0)
+#define WSTAMP(win, k) do {} while (0)
 #endif
 
 struct FusedLds {
@@ -28,30 +31,10 @@ struct FusedLds {
     float feats[TILE * FLD];
     float act[2][TILE * ALD1];
     float qv[TILE * 16];
+#ifdef MCTSQ_STAMPS
+    long long st[64], wst[64];
+#endif
 };
-
-// one GRU-attention window from staged weights to its 64 feature columns in LDS
-template <bool SAVE>
-__device__ __forceinline__ void run_window(GruWave<SAVE>& g, const GruSlot& s, GruLds& G, float* feats, int gtid,
-                                           int64_t row0, int64_t B, int64_t Bp, bool first) {
-    WSTAMP(0);
-    g.init(s);
-    g.stage(s, G, gtid, row0, B, Bp, first);
-    WSTAMP(1);
-    if (first) __syncthreads();                       // also publishes the zeroed arrival counters
-    else g.sync(G);
-    WSTAMP(2);
-    if (SAVE) g.save_window(s, G, gtid, row0, Bp);
-    g.run(s, G, row0, Bp);
-    WSTAMP(3);
-    WSTAMP(4);
-    g.fin0(G);
-    g.sync(G);
-    g.fin1(G);
-    g.sync(G);
-    g.fin2(s, G, feats + s.out_col, FLD, row0);
-    WSTAMP(5);
-}
 
 template <bool SAVE>
 __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadArgs ha) {
@@ -78,11 +61,45 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     STAMP(0);
     GruWave<SAVE> g;
     g.bind(lane, wq);
-    run_window<SAVE>(g, ga.slot[sa], G, L.feats, gtid, row0, ga.B, ga.Bp, true);
-    STAMP(1);
-    if (grp == 1) {
-        g.sync(G);                                    // every wave is done with the first window's LDS
-        run_window<SAVE>(g, ga.slot[sb], G, L.feats, gtid, row0, ga.B, ga.Bp, false);
+    // One copy of the window code serves both groups and both of group 1's windows (a loop, not two
+    // inlined call sites): half the instruction footprint, and the second window runs from a warm
+    // instruction cache.  The slot index is wave-uniform.
+    const int nwin = grp == 0 ? 1 : 2;
+    int si = __builtin_amdgcn_readfirstlane(sa);
+    WSTAMP(0, 0);
+    g.stage_issue(ga.slot[si], gtid, row0, ga.B);
+    g.init_weights(ga.slot[si]);
+    g.init_state();
+    g.stage_commit(ga.slot[si], G, gtid, row0, ga.B, ga.Bp, true);
+    WSTAMP(0, 1);
+    __syncthreads();                                  // also publishes the zeroed arrival counters
+    for (int wi = 0;; ++wi) {
+        const GruSlot& s = ga.slot[si];
+        WSTAMP(wi, 2);
+        if (SAVE) g.save_window(s, G, gtid, row0, ga.Bp);
+        g.run(s, G, row0, ga.Bp);
+        WSTAMP(wi, 3);
+        const bool more = wi + 1 < nwin;
+        const float lnw = g.lnwj, lnb = g.lnbj;
+        const int sn = __builtin_amdgcn_readfirstlane(sb);
+        // the next window's elements and weight fragments start their trip now, under this window's
+        // LayerNorm (init_weights touches none of its inputs)
+        if (more) { g.stage_issue(ga.slot[sn], gtid, row0, ga.B); g.init_weights(ga.slot[sn]); }
+        WSTAMP(wi, 5);
+        g.fin0(G);
+        WSTAMP(wi, 6);
+        g.sync(G);
+        WSTAMP(wi, 7);
+        g.fin2(s, G, L.feats + s.out_col, FLD, row0, lnw, lnb);
+        WSTAMP(wi, 4);
+        if (wi == 0) STAMP(1);
+        if (!more) break;
+        g.sync(G);                                    // every wave is done with this window's LDS
+        si = sn;
+        g.init_state();
+        g.stage_commit(ga.slot[si], G, gtid, row0, ga.B, ga.Bp, false);
+        WSTAMP(1, 1);
+        g.sync(G);
     }
     // The GRU registers are dead from here on.  Group 0 finishes first (25 steps against 10 + 3 and a
     // second staging): its waves fetch the head's weight fragments (two 16-column tiles of layers 0
@@ -208,6 +225,10 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         if (ha.argmax) ha.argmax[row] = arg;
     }
     STAMP(3);
+#ifdef MCTSQ_STAMPS
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1 && tid < 64) { g_stamps[tid] = L.st[tid]; g_iter[tid] = L.wst[tid]; }
+#endif
 }
 
 #ifdef MCTSQ_STAMPS

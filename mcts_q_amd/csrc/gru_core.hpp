@@ -56,6 +56,8 @@ struct GruWave {
     float att[4], mrun[4], lrun[4];
     bool bounded;                   // scores provably inside +-60 (log2 units): softmax without the running max
     float pooled[4], mean[4], rstd[4];
+    float xin[4], pdead;            // staged window elements in flight (stage_issue -> stage_commit); weight of a dead fold
+    float ab2, lnwj, lnbj;          // score bias (log2 units), LayerNorm scale / shift of unit j: fetched with the weights
     int lane, wq, jl, q, j, FP;
     unsigned nsync;
 
@@ -63,8 +65,13 @@ struct GruWave {
         lane = lane_; wq = wq_; jl = lane & 15; q = lane >> 4; j = 16 * wq + jl;
         nsync = 0;
     }
-    // weights and running sums of one window (a wave may run several windows one after another)
-    __device__ __forceinline__ void init(const GruSlot& s) {
+    // A wave may run several windows one after another.  Per window, in this order:
+    //   stage_issue   the window's elements -> registers (HBM round trip starts first)
+    //   init_weights  weight fragments -> registers; touches nothing the previous window's LayerNorm reads,
+    //                 so both can be issued BEFORE it and their latency hides under it
+    //   init_state    running sums (after the previous window's fin2)
+    //   stage_commit  registers -> LDS (after every wave of the group is done with the previous window's LDS)
+    __device__ __forceinline__ void init_weights(const GruSlot& s) {
         const int F = s.F;
         FP = F > 4 ? 8 : 4;
         const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep) + (int64_t)wq * (3 * 2 * 3 * 64) + lane;
@@ -91,6 +98,7 @@ struct GruWave {
             binv = (f32x4){bin, bin, bin, bin}; bhnv = (f32x4){bhn, bhn, bhn, bhn};
         }
         const float ab = s.ab[0] * LOG2E;                     // softmax evaluated in base 2
+        ab2 = ab; lnwj = s.lnw[j]; lnbj = s.lnb[j];
         awj = s.aw[j] * LOG2E;
         abl = (wq == 0 && jl == 0) ? ab : 0.0f;
         // |h| <= 1, so |score| <= sum_j |aw_j| + |ab|: when that bound is small exp2(score) can neither
@@ -103,7 +111,9 @@ struct GruWave {
         // yet ("dead" folds).  Bounded mode lets them run unconditionally: h_{-1} = h_{-2} = 0 adds nothing
         // to att, both dead scores are exactly ab (stage() seeds the slot the first one reads), and lrun
         // starts at minus their weight: -2p + p + p == 0 exactly.
-        const float pdead = fast_exp2(ab);
+        pdead = fast_exp2(ab);
+    }
+    __device__ __forceinline__ void init_state() {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             hh[0][r] = 0.0f; hh[1][r] = 0.0f; att[r] = 0.0f;
@@ -117,45 +127,66 @@ struct GruWave {
         group_sync(&L.arrivals, nsync, lane);
     }
 
-    // cooperative over the group's 256 lanes (gtid): xs[i][t*FP + f] (zero padded), h planes of buffer 0 = 0.
-    // The tile's 16 windows are one contiguous run of 16*S*Fd floats: every lane issues all its
-    // loads before the first use, so staging costs one memory round trip.  The caller follows with
-    // a WORKGROUP barrier (it also publishes the zeroed arrival counter).
-    __device__ __forceinline__ void stage(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t B, int64_t Bp,
-                                          bool first = true) {
-        const int S = s.S, F = s.F, Fd = s.Fd, SFd = S * Fd, sh = FP == 8 ? 3 : 2;
-        const int n = TILE * SFd;                             // <= 16 * 32 * 8 = 4096 = 16 per lane
+    // quotient e / d for 0 <= e < 2^22 with inv = 1 / d: the float estimate is off by at most one
+    static __device__ __forceinline__ int div_small(int e, int d, float inv) {
+        int qq = (int)((float)e * inv);
+        const int r = e - qq * d;
+        qq += r >= d ? 1 : 0;
+        qq -= r < 0 ? 1 : 0;
+        return qq;
+    }
+    // Staging, cooperative over the group's 256 lanes (gtid): xs[i][t*FP + f] (zero padded), h planes of
+    // buffer 0 = 0.  The tile's 16 windows are one contiguous run of 16*S*Fd floats; the first 1024 of
+    // them (all of them for every shipped window shape) travel through xin[].
+    __device__ __forceinline__ void stage_issue(const GruSlot& s, int gtid, int64_t row0, int64_t B) {
+        const int SFd = s.S * s.Fd, n = TILE * SFd;
         const float* src = s.x + row0 * (int64_t)SFd;
         const int64_t lim = (B - row0) * (int64_t)SFd;        // floats present in the batch
-        float v[4];
-        for (int e0 = 0; e0 < n; e0 += 1024) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 256 + gtid;
-                v[u] = (e < n && e < lim) ? src[e] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * 256 + gtid;
-                if (e < n) {
-                    const int i = e / SFd, rem = e - i * SFd, t = rem / Fd, f = rem - t * Fd;
-                    L.xs[i * XLD + (t << sh) + f] = v[u];
-                }
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int e = u * 256 + gtid;
+            xin[u] = (e < n && e < lim) ? src[e] : 0.0f;
         }
-        // columns Fd .. FP-1: time features of the non-_per flavour, then zero padding
-        const int npad = FP - Fd;
-        for (int idx = gtid; idx < TILE * S * npad; idx += 256) {
-            const int i = idx / (S * npad), rem = idx - i * (S * npad), t = rem / npad, f = Fd + rem - t * npad;
-            L.xs[i * XLD + (t << sh) + f] = (f < F && row0 + i < B) ? time_feature(s.tf, t, f - Fd) : 0.0f;
-        }
+    }
+    // The caller follows with a workgroup barrier (first window: it also publishes the zeroed arrival
+    // counter) or the group sync.
+    __device__ __forceinline__ void stage_commit(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t B, int64_t Bp,
+                                                 bool first = true) {
+        const int S = s.S, F = s.F, Fd = s.Fd, SFd = S * Fd, sh = FP == 8 ? 3 : 2;
+        const int n = TILE * SFd;                             // <= 16 * 32 * 8 = 4096
+        // everything that does not need the loaded elements first
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             for (int idx = gtid; idx < TILE * HLD / 2; idx += 256) reinterpret_cast<unsigned*>(L.hb[pl][0])[idx] = 0u;
-        if (gtid < 64) L.spart[0][gtid >> 4][gtid & 15] = gtid < 16 ? s.ab[0] * LOG2E : 0.0f;   // score of h_{-2}: ab
+        if (gtid < 64) L.spart[0][gtid >> 4][gtid & 15] = gtid < 16 ? ab2 : 0.0f;   // score of h_{-2}: ab
         if (first && gtid == 0) L.arrivals = 0;
+        // columns Fd .. FP-1: time features of the non-_per flavour, then zero padding
+        const int npad = FP - Fd, Snp = S * npad;
+        const float inv_snp = 1.0f / (float)max(Snp, 1), inv_np = 1.0f / (float)max(npad, 1);
+        for (int idx = gtid; idx < TILE * Snp; idx += 256) {
+            const int i = div_small(idx, Snp, inv_snp), rem = idx - i * Snp, t = div_small(rem, npad, inv_np);
+            const int f = Fd + rem - t * npad;
+            L.xs[i * XLD + (t << sh) + f] = (f < F && row0 + i < B) ? time_feature(s.tf, t, f - Fd) : 0.0f;
+        }
         if (SAVE)
             for (int idx = gtid; idx < TILE * E; idx += 256) s.sv_h[row0 * E + idx] = 0.0f;   // h_{-1}
+        const float inv_sfd = 1.0f / (float)SFd, inv_fd = 1.0f / (float)Fd;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = u * 256 + gtid;
+            if (e < n) {
+                const int i = div_small(e, SFd, inv_sfd), rem = e - i * SFd, t = div_small(rem, Fd, inv_fd);
+                L.xs[i * XLD + (t << sh) + rem - t * Fd] = xin[u];
+            }
+        }
+        if (n > 1024) {                                       // longer windows than any shipped configuration
+            const float* src = s.x + row0 * (int64_t)SFd;
+            const int64_t lim = (B - row0) * (int64_t)SFd;
+            for (int e = 1024 + gtid; e < n; e += 256) {
+                const int i = div_small(e, SFd, inv_sfd), rem = e - i * SFd, t = div_small(rem, Fd, inv_fd);
+                L.xs[i * XLD + (t << sh) + rem - t * Fd] = e < lim ? src[e] : 0.0f;
+            }
+        }
     }
     // training record of the staged window (time-major, 8 columns); call after the barrier
     __device__ __forceinline__ void save_window(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t Bp) {
@@ -318,33 +349,32 @@ struct GruWave {
         }
     }
 
-    // LayerNorm over the 64 hidden units (4 waves x 16 lanes) in three barrier-separated phases
+    // LayerNorm over the 64 hidden units (4 waves x 16 lanes) with ONE group sync: every wave publishes the
+    // sum and the centred sum of squares of its 16 units, and the four pairs are merged exactly
+    // (M2 = sum M2_w + 16 sum (mean_w - mean)^2) -- the accuracy of the two-pass form without its second sync.
     __device__ __forceinline__ void fin0(GruLds& L) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             pooled[r] = att[r] / lrun[r];
             const float ssum = row16_sum(pooled[r]);
-            if (jl == 0) L.red[0][wq][4 * q + r] = ssum;
+            const float d = pooled[r] - ssum * (1.0f / 16);
+            const float m2 = row16_sum(d * d);
+            if (jl == 0) { L.red[0][wq][4 * q + r] = ssum; L.red[1][wq][4 * q + r] = m2; }
         }
     }
-    __device__ __forceinline__ void fin1(GruLds& L) {
+    // after the sync: writes the normalised feature to out[i * ld + j] (LDS or global) and the training record
+    // (lnw, lnb: this window's lnwj / lnbj, read by the caller before a following window's init_weights)
+    __device__ __forceinline__ void fin2(const GruSlot& s, GruLds& L, float* out, int ld, int64_t row0, float lnw, float lnb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            mean[r] = ((L.red[0][0][i] + L.red[0][1][i]) + (L.red[0][2][i] + L.red[0][3][i])) * (1.0f / E);
-            const float d = pooled[r] - mean[r];
-            const float vs = row16_sum(d * d);
-            if (jl == 0) L.red[1][wq][i] = vs;
-        }
-    }
-    // writes the normalised feature to out[i * ld + j] (LDS or global) and the training record
-    __device__ __forceinline__ void fin2(const GruSlot& s, GruLds& L, float* out, int ld, int64_t row0) {
-        const float lnw = s.lnw[j], lnb = s.lnb[j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * q + r;
-            const float var = ((L.red[1][0][i] + L.red[1][1][i]) + (L.red[1][2][i] + L.red[1][3][i])) * (1.0f / E);
-            rstd[r] = 1.0f / sqrtf(var + LN_EPS);
+            const float s0 = L.red[0][0][i], s1 = L.red[0][1][i], s2 = L.red[0][2][i], s3 = L.red[0][3][i];
+            mean[r] = ((s0 + s1) + (s2 + s3)) * (1.0f / E);
+            const float d0 = s0 * (1.0f / 16) - mean[r], d1 = s1 * (1.0f / 16) - mean[r];
+            const float d2 = s2 * (1.0f / 16) - mean[r], d3 = s3 * (1.0f / 16) - mean[r];
+            const float m2 = ((L.red[1][0][i] + L.red[1][1][i]) + (L.red[1][2][i] + L.red[1][3][i])) +
+                             16.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            rstd[r] = 1.0f / sqrtf(m2 * (1.0f / E) + LN_EPS);
             out[i * ld + j] = (pooled[r] - mean[r]) * rstd[r] * lnw + lnb;
             if (SAVE) {
                 s.sv_pool[(row0 + i) * (int64_t)E + j] = pooled[r];

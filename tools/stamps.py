@@ -24,6 +24,7 @@ for w in range(8):
     print(w, d[:, w], "total", st[3, w] - st[0, w])
 it = out[64:64 + 32]
 for name, base in (("waves0-3 first", 0), ("waves4-7 first", 8), ("waves0-3 second", 16), ("waves4-7 second", 24)):
-    v = it[base:base + 6]
-    print(name, "start@%d" % (v[0] - st[0].min()), "init+stage, sync, loop, flush, LN:", np.diff(v))
+    v = it[base:base + 5]
+    print(name, "LN detail: prefetch issue, fin0, sync, fin2:", it[base + 5] - it[base + 3], it[base + 6] - it[base + 5], it[base + 7] - it[base + 6], it[base + 4] - it[base + 7])
+    print(name, "stamps (rel. kernel start; 0 = not taken):", np.where(v > 0, v - st[0].min(), 0), "init+stage, sync, loop, LN:", np.diff(v))
 print("kernel span (all waves):", st[3].max() - st[0].min())
