@@ -10,8 +10,17 @@
 
 namespace mctsq {
 
-constexpr int FLD = FEAT + 4;    // feature tile row stride in LDS
-constexpr int ALD1 = 128 + 4;    // hidden activation row stride
+constexpr int FPL = FEAT + 8;    // row stride (bf16 elements) of a feature plane: 400 B, b128 reads conflict-free
+constexpr int APL = 128 + 8;     // same for a hidden-activation plane (272 B)
+// prepared head weights (head_prepare_kernel), u32x4 fragments of 64 lanes each:
+//   layer 0 [tile 8][K chunk 6][plane 3], layer 1 [tile 8][K chunk 4][plane 3], output layer [K chunk 4][plane 3]
+constexpr int H0_FR = 8 * 6 * 3, H1_FR = 8 * 4 * 3, H2_FR = 4 * 3;
+static_assert(HEAD_PREP_BYTES == (int64_t)(H0_FR + H1_FR + H2_FR) * 64 * 16, "prepared head size");
+
+// six cross terms of the split product, smallest first
+#define HEAD_MM6(ACC, XH, XM, XL, W)                                                               \
+    ACC = mfma_bf(XL, (W)[0], ACC); ACC = mfma_bf(XH, (W)[2], ACC); ACC = mfma_bf(XM, (W)[1], ACC); \
+    ACC = mfma_bf(XM, (W)[0], ACC); ACC = mfma_bf(XH, (W)[1], ACC); ACC = mfma_bf(XH, (W)[0], ACC);
 
 // Diagnostic build (-DMCTSQ_STAMPS): s_memtime stamps of the LAST workgroup, kept in LDS while the kernel runs
 // (a global store per stamp queues behind the head-weight loads and distorts what it measures) and
@@ -28,8 +37,8 @@ __device__ long long g_iter[192];
 
 struct FusedLds {
     GruLds g[2];
-    float feats[TILE * FLD];
-    float act[2][TILE * ALD1];
+    unsigned short fpl[3][TILE * FPL];       // the 192 feature columns as bf16 planes (hi, mid, lo)
+    unsigned short apl[2][3][TILE * APL];    // hidden layers 0 and 1, same form
     float qv[TILE * 16];
 #ifdef MCTSQ_STAMPS
     long long st[64], wst[64];
@@ -79,21 +88,18 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         if (SAVE) g.save_window(s, G, gtid, row0, ga.Bp);
         g.run(s, G, row0, ga.Bp);
         WSTAMP(wi, 3);
-        const bool more = wi + 1 < nwin;
+        if (wi + 1 >= nwin) break;
         const float lnw = g.lnwj, lnb = g.lnbj;
         const int sn = __builtin_amdgcn_readfirstlane(sb);
         // the next window's elements and weight fragments start their trip now, under this window's
         // LayerNorm (init_weights touches none of its inputs)
-        if (more) { g.stage_issue(ga.slot[sn], gtid, row0, ga.B); g.init_weights(ga.slot[sn]); }
-        WSTAMP(wi, 5);
+        g.stage_issue(ga.slot[sn], gtid, row0, ga.B);
+        g.init_weights(ga.slot[sn]);
         g.fin0(G);
-        WSTAMP(wi, 6);
         g.sync(G);
-        WSTAMP(wi, 7);
-        g.fin2(s, G, L.feats + s.out_col, FLD, row0, lnw, lnb);
+        g.fin2_split(s, G, &L.fpl[0][0], TILE * FPL, FPL, row0, lnw, lnb, SAVE ? ga.feats : nullptr);
         WSTAMP(wi, 4);
-        if (wi == 0) STAMP(1);
-        if (!more) break;
+        STAMP(1);
         g.sync(G);                                    // every wave is done with this window's LDS
         si = sn;
         g.init_state();
@@ -101,90 +107,100 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         WSTAMP(1, 1);
         g.sync(G);
     }
-    // The GRU registers are dead from here on.  Group 0 finishes first (25 steps against 10 + 3 and a
-    // second staging): its waves fetch the head's weight fragments (two 16-column tiles of layers 0
-    // and 1 each; wave 0 also the output layer) while group 1 is still stepping:
-    // B[k = q*K4 + kk][col] = W[col][k].
-    const int ht = wave;
-    const bool head_wave = wave < 4;
-    float4 w0f[2][12], w1f[2][8], w2f[8];
-    if (head_wave) {
+    // The GRU weight registers are dead from here on: the head's fragments (prepared, lane-major, so every
+    // load instruction reads 1 KB in a row) take their place and travel under the last LayerNorm.
+    //   waves 0-3: layer 0, column tiles w and w + 4 (2 x 6 chunks x 3 planes); wave 0 also the output layer
+    //   waves 4-7: layer 1, column tiles w - 4 and w (2 x 4 x 3), needed only after layer 0 is through
+    const u32x4* hp = reinterpret_cast<const u32x4*>(ha.wprep) + lane;
+    const int ht = wave & 3;
+    u32x4 hw[2][18], hw2[12];
+    float hb[2];
+    if (wave < 4) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const float4* p0 = reinterpret_cast<const float4*>(ha.w[0] + (int64_t)(16 * (ht + 4 * tt) + jl) * FEAT + q * 48);
-            const float4* p1 = reinterpret_cast<const float4*>(ha.w[1] + (int64_t)(16 * (ht + 4 * tt) + jl) * 128 + q * 32);
 #pragma unroll
-            for (int c = 0; c < 12; ++c) w0f[tt][c] = p0[c];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) w1f[tt][c] = p1[c];
+            for (int f = 0; f < 18; ++f) hw[tt][f] = hp[((ht + 4 * tt) * 18 + f) * 64];
+            hb[tt] = ha.b[0][16 * (ht + 4 * tt) + jl];
         }
-        if (wave == 0) {
-            const float4* p2 = reinterpret_cast<const float4*>(ha.w[2] + (int64_t)(jl < ha.A ? jl : 0) * 128 + q * 32);
+    } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) w2f[c] = jl < ha.A ? p2[c] : make_float4(0, 0, 0, 0);
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int f = 0; f < 12; ++f) hw[tt][f] = hp[(H0_FR + (ht + 4 * tt) * 12 + f) * 64];
+            hb[tt] = ha.b[1][16 * (ht + 4 * tt) + jl];
         }
+    }
+    float hb2 = 0.0f;
+    if (wave == 0) {
+#pragma unroll
+        for (int f = 0; f < 12; ++f) hw2[f] = hp[(H0_FR + H1_FR + f) * 64];
+        hb2 = jl < ha.A ? ha.b[2][jl] : 0.0f;
+    }
+    {
+        const GruSlot& s = ga.slot[si];
+        WSTAMP(nwin - 1, 5);
+        g.fin0(G);
+        g.sync(G);
+        g.fin2_split(s, G, &L.fpl[0][0], TILE * FPL, FPL, row0, g.lnwj, g.lnbj, SAVE ? ga.feats : nullptr);
+        WSTAMP(nwin - 1, 4);
+        if (nwin == 1) STAMP(1);
     }
     __syncthreads();                                  // all three feature blocks are in LDS
     STAMP(2);
 
-    if (SAVE && ga.feats) {                           // training keeps the feature rows
-        for (int idx = tid; idx < TILE * FEAT; idx += 512) {
-            const int i = idx / FEAT, c = idx - i * FEAT;
-            ga.feats[(row0 + i) * (int64_t)FEAT + c] = L.feats[i * FLD + c];
-        }
-    }
-
-    // ---- head layer 0: [16 x 192] . W0^T, two column tiles per wave 0..3 ------------------
-    if (head_wave) {
-        const float4* xa = reinterpret_cast<const float4*>(&L.feats[(lane & 15) * FLD + q * 48]);
-        f32x4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    // ---- head layer 0: [16 x 192] . W0^T on waves 0-3, two column tiles each ----------------
+    // All three layers run on the bf16 matrix instruction over the exact three-way split of both operands
+    // (six cross terms, fp32 accumulate on top of the bias); activations are split by the lanes that produce them.
+    if (wave < 4) {
+        f32x4 acc[2][2] = {{{hb[0], hb[0], hb[0], hb[0]}, {0, 0, 0, 0}}, {{hb[1], hb[1], hb[1], hb[1]}, {0, 0, 0, 0}}};
+        const int o = (lane & 15) * FPL + 8 * q;
 #pragma unroll
-        for (int c = 0; c < 12; c += 2) {
-            const float4 a = xa[c], b = xa[c + 1];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                acc[tt][0] = mfma16(a.x, w0f[tt][c].x, acc[tt][0]); acc[tt][1] = mfma16(b.x, w0f[tt][c + 1].x, acc[tt][1]);
-                acc[tt][0] = mfma16(a.y, w0f[tt][c].y, acc[tt][0]); acc[tt][1] = mfma16(b.y, w0f[tt][c + 1].y, acc[tt][1]);
-                acc[tt][0] = mfma16(a.z, w0f[tt][c].z, acc[tt][0]); acc[tt][1] = mfma16(b.z, w0f[tt][c + 1].z, acc[tt][1]);
-                acc[tt][0] = mfma16(a.w, w0f[tt][c].w, acc[tt][0]); acc[tt][1] = mfma16(b.w, w0f[tt][c + 1].w, acc[tt][1]);
-            }
+        for (int c = 0; c < 6; ++c) {
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(&L.fpl[0][o + 32 * c]);
+            const u32x4 xm = *reinterpret_cast<const u32x4*>(&L.fpl[1][o + 32 * c]);
+            const u32x4 xl = *reinterpret_cast<const u32x4*>(&L.fpl[2][o + 32 * c]);
+            HEAD_MM6(acc[0][c & 1], xh, xm, xl, &hw[0][3 * c])
+            HEAD_MM6(acc[1][c & 1], xh, xm, xl, &hw[1][3 * c])
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int col = 16 * (ht + 4 * tt) + jl;
-            const float bias = ha.b[0][col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = apply_act((acc[tt][0][r] + acc[tt][1][r]) + bias, ha.act);
-                L.act[0][(4 * q + r) * ALD1 + col] = v;
+                const float v = apply_act(acc[tt][0][r] + acc[tt][1][r], ha.act);
+                unsigned u0, u1, u2;
+                split3(v, u0, u1, u2);
+                L.apl[0][0][(4 * q + r) * APL + col] = (unsigned short)(u0 >> 16);
+                L.apl[0][1][(4 * q + r) * APL + col] = (unsigned short)(u1 >> 16);
+                L.apl[0][2][(4 * q + r) * APL + col] = (unsigned short)(u2 >> 16);
                 if (SAVE) ha.sv_act[0][(row0 + 4 * q + r) * (int64_t)128 + col] = v;
             }
         }
     }
     __syncthreads();
-    // ---- head layer 1: [16 x 128] . W1^T ---------------------------------------------------
-    if (head_wave) {
-        const float4* xa = reinterpret_cast<const float4*>(&L.act[0][(lane & 15) * ALD1 + q * 32]);
-        f32x4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+    // ---- head layer 1: [16 x 128] . W1^T on waves 4-7 ----------------------------------------
+    if (wave >= 4) {
+        f32x4 acc[2][2] = {{{hb[0], hb[0], hb[0], hb[0]}, {0, 0, 0, 0}}, {{hb[1], hb[1], hb[1], hb[1]}, {0, 0, 0, 0}}};
+        const int o = (lane & 15) * APL + 8 * q;
 #pragma unroll
-        for (int c = 0; c < 8; c += 2) {
-            const float4 a = xa[c], b = xa[c + 1];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                acc[tt][0] = mfma16(a.x, w1f[tt][c].x, acc[tt][0]); acc[tt][1] = mfma16(b.x, w1f[tt][c + 1].x, acc[tt][1]);
-                acc[tt][0] = mfma16(a.y, w1f[tt][c].y, acc[tt][0]); acc[tt][1] = mfma16(b.y, w1f[tt][c + 1].y, acc[tt][1]);
-                acc[tt][0] = mfma16(a.z, w1f[tt][c].z, acc[tt][0]); acc[tt][1] = mfma16(b.z, w1f[tt][c + 1].z, acc[tt][1]);
-                acc[tt][0] = mfma16(a.w, w1f[tt][c].w, acc[tt][0]); acc[tt][1] = mfma16(b.w, w1f[tt][c + 1].w, acc[tt][1]);
-            }
+        for (int c = 0; c < 4; ++c) {
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(&L.apl[0][0][o + 32 * c]);
+            const u32x4 xm = *reinterpret_cast<const u32x4*>(&L.apl[0][1][o + 32 * c]);
+            const u32x4 xl = *reinterpret_cast<const u32x4*>(&L.apl[0][2][o + 32 * c]);
+            HEAD_MM6(acc[0][c & 1], xh, xm, xl, &hw[0][3 * c])
+            HEAD_MM6(acc[1][c & 1], xh, xm, xl, &hw[1][3 * c])
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int col = 16 * (ht + 4 * tt) + jl;
-            const float bias = ha.b[1][col];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = apply_act((acc[tt][0][r] + acc[tt][1][r]) + bias, ha.act);
-                L.act[1][(4 * q + r) * ALD1 + col] = v;
+                const float v = apply_act(acc[tt][0][r] + acc[tt][1][r], ha.act);
+                unsigned u0, u1, u2;
+                split3(v, u0, u1, u2);
+                L.apl[1][0][(4 * q + r) * APL + col] = (unsigned short)(u0 >> 16);
+                L.apl[1][1][(4 * q + r) * APL + col] = (unsigned short)(u1 >> 16);
+                L.apl[1][2][(4 * q + r) * APL + col] = (unsigned short)(u2 >> 16);
                 if (SAVE) ha.sv_act[1][(row0 + 4 * q + r) * (int64_t)128 + col] = v;
             }
         }
@@ -192,19 +208,21 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     __syncthreads();
     // ---- output layer: [16 x 128] . W2^T (A <= 16 columns), wave 0 -------------------------
     if (wave == 0) {
-        const float4* xa = reinterpret_cast<const float4*>(&L.act[1][(lane & 15) * ALD1 + q * 32]);
-        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        f32x4 acc0 = {hb2, hb2, hb2, hb2}, acc1 = {0, 0, 0, 0};
+        const int o = (lane & 15) * APL + 8 * q;
 #pragma unroll
-        for (int c = 0; c < 8; c += 2) {
-            const float4 a = xa[c], b = xa[c + 1];
-            acc0 = mfma16(a.x, w2f[c].x, acc0); acc1 = mfma16(b.x, w2f[c + 1].x, acc1);
-            acc0 = mfma16(a.y, w2f[c].y, acc0); acc1 = mfma16(b.y, w2f[c + 1].y, acc1);
-            acc0 = mfma16(a.z, w2f[c].z, acc0); acc1 = mfma16(b.z, w2f[c + 1].z, acc1);
-            acc0 = mfma16(a.w, w2f[c].w, acc0); acc1 = mfma16(b.w, w2f[c + 1].w, acc1);
+        for (int c = 0; c < 4; c += 2) {
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(&L.apl[1][0][o + 32 * c]);
+            const u32x4 xm = *reinterpret_cast<const u32x4*>(&L.apl[1][1][o + 32 * c]);
+            const u32x4 xl = *reinterpret_cast<const u32x4*>(&L.apl[1][2][o + 32 * c]);
+            const u32x4 yh = *reinterpret_cast<const u32x4*>(&L.apl[1][0][o + 32 * c + 32]);
+            const u32x4 ym = *reinterpret_cast<const u32x4*>(&L.apl[1][1][o + 32 * c + 32]);
+            const u32x4 yl = *reinterpret_cast<const u32x4*>(&L.apl[1][2][o + 32 * c + 32]);
+            HEAD_MM6(acc0, xh, xm, xl, &hw2[3 * c])
+            HEAD_MM6(acc1, yh, ym, yl, &hw2[3 * c + 3])
         }
-        const float bias = jl < ha.A ? ha.b[2][jl] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.qv[(4 * q + r) * 16 + jl] = (acc0[r] + acc1[r]) + bias;
+        for (int r = 0; r < 4; ++r) L.qv[(4 * q + r) * 16 + jl] = acc0[r] + acc1[r];
     }
     __syncthreads();
     // ---- leaf epilogue: one lane per sample ---------------------------------------------
@@ -240,6 +258,36 @@ extern "C" int mctsq_debug_stamps(long long* host_out) {
 
 int check_gru_args(const GruFwdArgs& args);
 
+// Head weights -> split-bf16 B fragments in the order the fused kernel loads them: lane (jl, q) of fragment
+// (tile, chunk c) holds W[16 tile + jl][32c + 8q .. +7]; rows >= A of the output layer are zero.
+__global__ __launch_bounds__(256) void head_prepare_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, int A, u32x4* __restrict__ out) {
+    const int tid = blockIdx.x * 256 + threadIdx.x, lane = tid & 63, fg = tid >> 6;
+    if (fg >= 48 + 32 + 4) return;
+    const int jl = lane & 15, q = lane >> 4;
+    const float* w;
+    int K, tile, c, base;
+    bool valid = true;
+    if (fg < 48) { w = w0; K = FEAT; tile = fg / 6; c = fg % 6; base = fg * 3; }
+    else if (fg < 80) { const int f = fg - 48; w = w1; K = 128; tile = f / 4; c = f % 4; base = H0_FR + f * 3; }
+    else { const int f = fg - 80; w = w2; K = 128; tile = 0; c = f; base = H0_FR + H1_FR + f * 3; valid = jl < A; }
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (valid) {
+        const float4* p = reinterpret_cast<const float4*>(w + (int64_t)(16 * tile + jl) * K + 32 * c + 8 * q);
+        a = p[0]; b = p[1];
+    }
+    u32x4 hi, mid, lo;
+    split8(a, b, hi, mid, lo);
+    out[(base + 0) * 64 + lane] = hi; out[(base + 1) * 64 + lane] = mid; out[(base + 2) * 64 + lane] = lo;
+}
+int launch_head_prepare(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st) {
+    MCTSQ_CHECK(w0 && w1 && w2 && prep && A >= 1 && A <= 16, "head prepare: bad arguments");
+    hipLaunchKernelGGL(head_prepare_kernel, dim3((84 * 64 + 255) / 256), dim3(256), 0, st, w0, w1, w2, A,
+                       reinterpret_cast<u32x4*>(prep));
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 bool fused_gru_head_applicable(const GruFwdArgs& ga, const HeadArgs& ha) {
     return ga.nslots == 3 && ha.n_fc == 3 && ha.in[0] == FEAT && ha.out[0] == 128 && ha.in[1] == 128 &&
            ha.out[1] == 128 && ha.in[2] == 128 && ha.A <= 16 && ga.slot[0].out_col == 0 &&
@@ -250,6 +298,7 @@ int launch_gru3_head_fwd(const GruFwdArgs& ga, const HeadArgs& ha, bool save, hi
     if (ga.B == 0) return 0;
     if (check_gru_args(ga)) return -1;
     MCTSQ_CHECK(fused_gru_head_applicable(ga, ha), "fused GRU+head kernel needs gru/gru/gru and a 192-128-128-A head");
+    MCTSQ_CHECK(ha.wprep, "fused GRU+head kernel needs the prepared head weights");
     dim3 grid((unsigned)(ga.Bp / TILE));
     if (save) hipLaunchKernelGGL(gru3_head_fwd_kernel<true>, grid, dim3(512), 0, st, ga, ha);
     else hipLaunchKernelGGL(gru3_head_fwd_kernel<false>, grid, dim3(512), 0, st, ga, ha);

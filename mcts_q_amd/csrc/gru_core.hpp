@@ -385,6 +385,38 @@ struct GruWave {
             }
         }
     }
+    // fin2 for a consumer that multiplies on the bf16 matrix instruction: the normalised feature goes to three
+    // bf16 planes (hi, mid, lo; `pstride` elements apart, row stride `ld`) at column out_col + j, and -- training --
+    // to the global feature rows gfeats [Bp][192]
+    __device__ __forceinline__ void fin2_split(const GruSlot& s, GruLds& L, unsigned short* planes, int pstride, int ld,
+                                               int64_t row0, float lnw, float lnb, float* gfeats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            const float s0 = L.red[0][0][i], s1 = L.red[0][1][i], s2 = L.red[0][2][i], s3 = L.red[0][3][i];
+            mean[r] = ((s0 + s1) + (s2 + s3)) * (1.0f / E);
+            const float d0 = s0 * (1.0f / 16) - mean[r], d1 = s1 * (1.0f / 16) - mean[r];
+            const float d2 = s2 * (1.0f / 16) - mean[r], d3 = s3 * (1.0f / 16) - mean[r];
+            const float m2 = ((L.red[1][0][i] + L.red[1][1][i]) + (L.red[1][2][i] + L.red[1][3][i])) +
+                             16.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            rstd[r] = 1.0f / sqrtf(m2 * (1.0f / E) + LN_EPS);
+            const float v = (pooled[r] - mean[r]) * rstd[r] * lnw + lnb;
+            unsigned u0, u1, u2;
+            split3(v, u0, u1, u2);
+            unsigned short* dst = planes + i * ld + s.out_col + j;
+            dst[0] = (unsigned short)(u0 >> 16);
+            dst[pstride] = (unsigned short)(u1 >> 16);
+            dst[2 * pstride] = (unsigned short)(u2 >> 16);
+            if (SAVE) {
+                if (gfeats) gfeats[(row0 + i) * (int64_t)FEAT + s.out_col + j] = v;
+                s.sv_pool[(row0 + i) * (int64_t)E + j] = pooled[r];
+                if (wq == 0 && jl == 0) {
+                    float* st = s.sv_stat + (row0 + i) * 4;
+                    st[0] = mrun[r]; st[1] = lrun[r]; st[2] = mean[r]; st[3] = rstd[r];
+                }
+            }
+        }
+    }
 };
 
 }  // namespace mctsq

@@ -119,11 +119,15 @@ struct HeadArgs {
     float *q, *vmax, *prior;             // [B][A], [B], [B][A]; vmax/prior may be NULL
     int32_t* argmax;                     // [B] or NULL
     float* sv_act[4];                    // training: post-activation hidden layers [Bp][H] or NULL
+    const void* wprep;                   // fused kernel only: split-bf16 weight fragments (head_prepare_kernel)
 };
 int launch_head_fwd(const HeadArgs& args, hipStream_t st);
 
 // gru/gru/gru + 192-128-128-A head in one launch (fused_gru_head.hip)
 bool fused_gru_head_applicable(const GruFwdArgs& ga, const HeadArgs& ha);
+// the three head layers as split-bf16 B fragments: 8x6x3 + 8x4x3 + 4x3 fragments of 64 lanes x 16 B
+constexpr int64_t HEAD_PREP_BYTES = (int64_t)(8 * 6 * 3 + 8 * 4 * 3 + 4 * 3) * 64 * 16;
+int launch_head_prepare(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st);
 int launch_gru3_head_fwd(const GruFwdArgs& ga, const HeadArgs& ha, bool save, hipStream_t st);
 
 }  // namespace mctsq
