@@ -74,6 +74,20 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_row<0x121>(v);
     return v;
 }
+__device__ __forceinline__ float row16_max_dpp(float v) {
+    v = fmaxf(v, dpp_row<0x128>(v));
+    v = fmaxf(v, dpp_row<0x124>(v));
+    v = fmaxf(v, dpp_row<0x122>(v));
+    v = fmaxf(v, dpp_row<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_min_dpp(float v) {
+    v = fminf(v, dpp_row<0x128>(v));
+    v = fminf(v, dpp_row<0x124>(v));
+    v = fminf(v, dpp_row<0x122>(v));
+    v = fminf(v, dpp_row<0x121>(v));
+    return v;
+}
 __device__ __forceinline__ float row16_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 1, 64));
     v = fmaxf(v, __shfl_xor(v, 2, 64));

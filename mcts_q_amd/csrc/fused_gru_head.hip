@@ -39,7 +39,6 @@ struct FusedLds {
     GruLds g[2];
     unsigned short fpl[3][TILE * FPL];       // the 192 feature columns as bf16 planes (hi, mid, lo)
     unsigned short apl[2][3][TILE * APL];    // hidden layers 0 and 1, same form
-    float qv[TILE * 16];
 #ifdef MCTSQ_STAMPS
     long long st[64], wst[64];
 #endif
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     }
     // The GRU weight registers are dead from here on: the head's fragments (prepared, lane-major, so every
     // load instruction reads 1 KB in a row) take their place and travel under the last LayerNorm.
-    //   waves 0-3: layer 0, column tiles w and w + 4 (2 x 6 chunks x 3 planes); wave 0 also the output layer
+    //   waves 0-3: layer 0, column tiles w and w + 4 (2 x 6 chunks x 3 planes), and the output layer (4 x 3)
     //   waves 4-7: layer 1, column tiles w - 4 and w (2 x 4 x 3), needed only after layer 0 is through
     const u32x4* hp = reinterpret_cast<const u32x4*>(ha.wprep) + lane;
     const int ht = wave & 3;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         }
     }
     float hb2 = 0.0f;
-    if (wave == 0) {
+    if (wave < 4) {
 #pragma unroll
         for (int f = 0; f < 12; ++f) hw2[f] = hp[(H0_FR + H1_FR + f) * 64];
         hb2 = jl < ha.A ? ha.b[2][jl] : 0.0f;
@@ -206,8 +205,10 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         }
     }
     __syncthreads();
-    // ---- output layer: [16 x 128] . W2^T (A <= 16 columns), wave 0 -------------------------
-    if (wave == 0) {
+    // ---- output layer: [16 x 128] . W2^T (A <= 16 columns).  Waves 0-3 all form the full product (24 matrix
+    // instructions, side by side on the four SIMDs) and each finishes one of the lane's four rows: the
+    // epilogue is a serial dependency chain, so four short ones beat one long one.
+    if (wave < 4) {
         f32x4 acc0 = {hb2, hb2, hb2, hb2}, acc1 = {0, 0, 0, 0};
         const int o = (lane & 15) * APL + 8 * q;
 #pragma unroll
@@ -221,26 +222,28 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
             HEAD_MM6(acc0, xh, xm, xl, &hw2[3 * c])
             HEAD_MM6(acc1, yh, ym, yl, &hw2[3 * c + 3])
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) L.qv[(4 * q + r) * 16 + jl] = acc0[r] + acc1[r];
-    }
-    __syncthreads();
-    // ---- leaf epilogue: one lane per sample ---------------------------------------------
-    if (tid < TILE && row0 + tid < ha.B) {
-        const float* qv = &L.qv[tid * 16];
-        const int64_t row = row0 + tid;
-        float best = qv[0];
-        int arg = 0;
-        for (int k = 1; k < ha.A; ++k)
-            if (qv[k] > best) { best = qv[k]; arg = k; }       // first maximum, like torch.argmax
-        float den = 0.0f;
-        for (int k = 0; k < ha.A; ++k) den += expf(qv[k] - best);
-        for (int k = 0; k < ha.A; ++k) {
-            ha.q[row * ha.A + k] = qv[k];
-            if (ha.prior) ha.prior[row * ha.A + k] = expf(qv[k] - best) / den;
+        // ---- leaf epilogue in registers: lane (jl, q) holds Q[row 4q + r][action jl]; max / first argmax /
+        // softmax (mcts_per.py:293, 370) are reductions over the 16 lanes of a row group
+        const bool colok = jl < ha.A;
+        {
+            const int r = ht;
+            const int64_t row = row0 + 4 * q + r;
+            const float v = r == 0 ? acc0[0] + acc1[0] : r == 1 ? acc0[1] + acc1[1] : r == 2 ? acc0[2] + acc1[2] : acc0[3] + acc1[3];
+            const float best = row16_max_dpp(colok ? v : -INFINITY);
+            const float first = row16_min_dpp((colok && v == best) ? (float)jl : 99.0f);   // like torch.argmax
+            const float e = colok ? expf(v - best) : 0.0f;
+            const float den = row16_sum(e);
+            if (row < ha.B) {
+                if (colok) {
+                    ha.q[row * ha.A + jl] = v;
+                    if (ha.prior) ha.prior[row * ha.A + jl] = e / den;
+                }
+                if (jl == 0) {
+                    if (ha.vmax) ha.vmax[row] = best;
+                    if (ha.argmax) ha.argmax[row] = (int)first;
+                }
+            }
         }
-        if (ha.vmax) ha.vmax[row] = best;
-        if (ha.argmax) ha.argmax[row] = arg;
     }
     STAMP(3);
 #ifdef MCTSQ_STAMPS
