@@ -47,12 +47,9 @@ struct FusedLds {
 template <bool SAVE>
 __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadArgs ha) {
     __shared__ __attribute__((aligned(16))) FusedLds L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef MCTSQ_EXP_SWAP
-    const int grp = (wave >> 2) ^ 1, wq = wave & 3, gtid = tid & 255;
-#else
+    // the wave index (and everything derived from it: group, unit block, head tile) lives in scalar registers
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3, gtid = tid & 255;
-#endif
     const int jl = lane & 15, q = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * TILE;
     GruLds& G = L.g[grp];
@@ -113,7 +110,7 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     const u32x4* hp = reinterpret_cast<const u32x4*>(ha.wprep) + lane;
     const int ht = wave & 3;
     u32x4 hw[2][18], hw2[12];
-    float hb[2];
+    float hb[2], hb2 = 0.0f;
     if (wave < 4) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -128,12 +125,6 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
             for (int f = 0; f < 12; ++f) hw[tt][f] = hp[(H0_FR + (ht + 4 * tt) * 12 + f) * 64];
             hb[tt] = ha.b[1][16 * (ht + 4 * tt) + jl];
         }
-    }
-    float hb2 = 0.0f;
-    if (wave < 4) {
-#pragma unroll
-        for (int f = 0; f < 12; ++f) hw2[f] = hp[(H0_FR + H1_FR + f) * 64];
-        hb2 = jl < ha.A ? ha.b[2][jl] : 0.0f;
     }
     {
         const GruSlot& s = ga.slot[si];
@@ -175,6 +166,10 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
                 if (SAVE) ha.sv_act[0][(row0 + 4 * q + r) * (int64_t)128 + col] = v;
             }
         }
+        // layer 0's fragments are dead: the output layer's take their registers and arrive while waves 4-7 run layer 1
+#pragma unroll
+        for (int f = 0; f < 12; ++f) hw2[f] = hp[(H0_FR + H1_FR + f) * 64];
+        hb2 = jl < ha.A ? ha.b[2][jl] : 0.0f;
     }
     __syncthreads();
     // ---- head layer 1: [16 x 128] . W1^T on waves 4-7 ----------------------------------------
@@ -224,6 +219,8 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
         }
         // ---- leaf epilogue in registers: lane (jl, q) holds Q[row 4q + r][action jl]; max / first argmax /
         // softmax (mcts_per.py:293, 370) are reductions over the 16 lanes of a row group
+        // (lane position re-derived here: values computed at kernel entry would sit in registers across every loop)
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), jl = ln & 15, q = ln >> 4;
         const bool colok = jl < ha.A;
         {
             const int r = ht;

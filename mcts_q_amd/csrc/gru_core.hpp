@@ -179,12 +179,16 @@ struct GruWave {
                 L.xs[i * XLD + (t << sh) + rem - t * Fd] = xin[u];
             }
         }
-        if (n > 1024) {                                       // longer windows than any shipped configuration
+        for (int e0 = 1024; e0 < n; e0 += 1024) {             // longer windows than any shipped configuration
             const float* src = s.x + row0 * (int64_t)SFd;
             const int64_t lim = (B - row0) * (int64_t)SFd;
-            for (int e = 1024 + gtid; e < n; e += 256) {
-                const int i = div_small(e, SFd, inv_sfd), rem = e - i * SFd, t = div_small(rem, Fd, inv_fd);
-                L.xs[i * XLD + (t << sh) + rem - t * Fd] = e < lim ? src[e] : 0.0f;
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 256 + gtid;
+                if (e < n) {
+                    const int i = div_small(e, SFd, inv_sfd), rem = e - i * SFd, t = div_small(rem, Fd, inv_fd);
+                    L.xs[i * XLD + (t << sh) + rem - t * Fd] = e < lim ? src[e] : 0.0f;
+                }
             }
         }
     }

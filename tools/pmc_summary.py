@@ -21,6 +21,6 @@ res["correction"] = ("FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B, 
                      "WRITE_SIZE as is; KB = 1024 B")
 res["hbm_bytes_per_launch"] = (2 * res["FETCH_SIZE_KB_avg"] + res["WRITE_SIZE_KB_avg"]) * 1024
 res["command"] = ("rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- python3 bench.py "
-                  "--steps 10 --warmup 2 --no-cpu-baseline --no-train  (tools/profile_bench.sh)")
+                  "--steps 10 --warmup 2 --no-cpu-baseline --no-train --no-trees  (tools/profile_bench.sh)")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))
