@@ -216,9 +216,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_GBs_algorithmic": alg_bytes / (k_ms * 1e-3) / 1e9,
                 "note": "intensity ~2.5 kFLOP/B: matrix/vector issue bounds it, not HBM.  achieved = ALGORITHMIC fp32 "
-                        "FLOPs / time against the dense fp32 MFMA peak; the recurrent products run as six bf16 "
-                        "MFMAs on an exact 3-way split of both operands (fp32-accurate, 6 x the executed matrix "
-                        "FLOPs at 16 x the rate), input projections and head on v_mfma_f32_16x16x4_f32"}
+                        "FLOPs / time against the dense fp32 MFMA peak; the recurrent products and the head run "
+                        "as six bf16 MFMAs on an exact 3-way split of both operands (fp32-accurate, 6 x the executed "
+                        "matrix FLOPs at 16 x the rate), the input projections on v_mfma_f32_16x16x4_f32"}
 
     # --- PER-DQN train steps (config 3), data-parallel over ranks ---------------------------------
     train = None

@@ -86,8 +86,9 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
                        float* d_vmax, int32_t* d_argmax, float* d_prior, void* d_ws,
                        int64_t ws_bytes, void* stream, void* ev_encoders_done);
 
-/* ---- prepared weights.  The GRU recurrence multiplies by W_hh through the bf16 matrix instruction
- * on an exact three-way split of every fp32 weight.  mctsq_q_forward splits
+/* ---- prepared weights.  The GRU recurrence (W_hh), the transformer FFN and the head of the fused
+ * gru/gru/gru kernel multiply through the bf16 matrix instruction on an exact three-way split of
+ * every fp32 weight.  mctsq_q_forward splits
  * the weights into its workspace on every call; a caller whose parameters stay fixed over many
  * evaluations (MCTS leaf evaluation between learner steps, mctsq_config_mcts_per.py:291-296,
  * 367-370) prepares them once and calls mctsq_q_forward_prepared.  d_prep: mctsq_q_prepared_bytes

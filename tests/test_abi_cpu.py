@@ -33,7 +33,7 @@ def test_host_side_queries_need_no_gpu():
     spec = NetSpec.from_cfg(dict(price="gru", process="gru", gas="gru", act="relu", flavor="per"))
     d = spec.c_desc()
     lib = _lib.lib
-    assert lib.mctsq_q_prepared_bytes(ctypes.byref(d)) == 3 * 4 * 3 * 2 * 3 * 64 * 16
+    assert lib.mctsq_q_prepared_bytes(ctypes.byref(d)) == (3 * 4 * 3 * 2 * 3 + 8 * 6 * 3 + 8 * 4 * 3 + 4 * 3) * 64 * 16   # W_hh x 3 + head layers
     assert lib.mctsq_q_forward_workspace_bytes(ctypes.byref(d), 4096) > 4096 * 192 * 4
     assert lib.mctsq_per_tree_words(1_000_000) > 1_000_000
     assert lib.mctsq_q_forward_workspace_bytes(ctypes.byref(d), -1) < 0
