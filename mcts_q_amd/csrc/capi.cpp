@@ -88,7 +88,7 @@ static int64_t gru_prepared_bytes(const NetLayout& L) {
 static int64_t tf_prepared_bytes(const NetLayout& L) {
     int n = 0;
     for (int s = 0; s < 3; ++s) n += L.enc[s].kind == MCTSQ_ENC_TRANSFORMER;
-    return 2 * n * TF_FFN_PREP_BYTES;
+    return 2 * n * TF_LAYER_PREP_BYTES;
 }
 // the network the fused GRU + head kernel serves (fused_gru_head_applicable, in terms of the layout)
 static bool fused_layout(const NetLayout& L) {
@@ -113,8 +113,8 @@ int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_
         if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
         for (int l = 0; l < 2; ++l) {
             const TfLayerOff& o = L.enc[s].tfm.layer[l];
-            if (launch_tf_prepare(params + o.l1w, params + o.l2w, p, st)) return -1;
-            p += TF_FFN_PREP_BYTES;
+            if (launch_tf_prepare(params + o.l1w, params + o.l2w, params + o.inw, params + o.ow, p, st)) return -1;
+            p += TF_LAYER_PREP_BYTES;
         }
     }
     if (fused_layout(L) &&
@@ -136,7 +136,7 @@ void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* 
         w.n1w = params + o.n1w; w.n1b = params + o.n1b; w.n2w = params + o.n2w; w.n2b = params + o.n2b;
     }
     t.lnw = params + e.tfm.lnw; t.lnb = params + e.tfm.lnb;
-    t.S = e.S; t.Fd = e.Fd; t.F = e.F; t.tf = e.tf; t.out_col = slot * E; t.NS = 128 / e.S;
+    t.S = e.S; t.Fd = e.Fd; t.F = e.F; t.tf = e.tf; t.out_col = slot * E; t.NS = 64 / e.S;
     t.B = B; t.Bvalid = B; t.Bp = Bp; t.T = B * e.S; t.Tp = tf_padded_tokens(Bp, e.S);
     float *h0 = hbuf, *h1 = hbuf + t.Tp * E;                  // inference: ping-pong
     for (int l = 0; l < 2; ++l) { t.buf[l].hin = h0; t.buf[l].hmid = h1; t.buf[l].hout = h0; }
@@ -193,7 +193,7 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
             if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
             TfArgs t;
             fill_tf_args(t, L.enc[s], params, x[s], s, B, Bp, feats, hbuf, sv ? &sv[s] : nullptr);
-            for (int l = 0; l < 2; ++l) { t.ffn_prep[l] = tprep; tprep += TF_FFN_PREP_BYTES; }
+            for (int l = 0; l < 2; ++l) { t.ffn_prep[l] = tprep; tprep += TF_LAYER_PREP_BYTES; }
             if (launch_tf_fwd(t, st)) return -1;
             hbuf += 2 * t.Tp * E;
         }

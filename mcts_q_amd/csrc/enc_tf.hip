@@ -60,13 +60,21 @@ __device__ __forceinline__ void ln_rows(float x[4][4], const float* lnw, const f
     }
 }
 
-// ------------------------------------------------------------------------------ attention block
-// One workgroup = NS whole samples (NS*S <= 128 token rows).  h -> in_proj (q|k|v) -> per (sample,
-// head) softmax(q k^T / 4) v -> out_proj -> + h -> LayerNorm1.
-constexpr int AHLD = 68, QLD = 196, AROWS = 128;
+constexpr int FFN_FRAGS = 24, FFN_PAIRS = FF / 32;
+// six cross terms of the split product, smallest first
+#define TF_MM6(ACC, XH, XM, XL, YH, YM, YL)                                              \
+    ACC = mfma_bf(XL, YH, ACC); ACC = mfma_bf(XH, YL, ACC); ACC = mfma_bf(XM, YM, ACC);   \
+    ACC = mfma_bf(XM, YH, ACC); ACC = mfma_bf(XH, YM, ACC); ACC = mfma_bf(XH, YH, ACC);
 
-__global__ __launch_bounds__(512) void tf_attn_kernel(TfArgs a, int layer) {
-    __shared__ __attribute__((aligned(16))) float hs[AROWS * AHLD];
+// ------------------------------------------------------------------------------ attention block
+// One workgroup = NS whole samples (NS*S <= 64 token rows), 4 waves, one 16-row tile each.
+// h -> in_proj (q|k|v) -> per (sample, head) softmax(q k^T / 4) v -> out_proj -> + h -> LayerNorm1.
+// Only q|k|v lives in LDS (49 KB), so three workgroups share a CU and their phases (global fetch, matrix work,
+// the latency-bound per-head softmax, LayerNorm) overlap; the A fragments of in_proj and the residual rows come
+// straight from global memory.
+constexpr int QLD = 196, AROWS = 64;
+
+__global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
     __shared__ __attribute__((aligned(16))) float qkv[AROWS * QLD];
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
@@ -79,39 +87,34 @@ __global__ __launch_bounds__(512) void tf_attn_kernel(TfArgs a, int layer) {
     const int rows = ns * S;
     const int64_t tok0 = sample0 * S;
 
-    for (int idx = tid; idx < AROWS * 16; idx += 512) {
-        const int r = idx >> 4, c4 = idx & 15;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (r < rows) v = reinterpret_cast<const float4*>(hin + (tok0 + r) * E)[c4];
-        *reinterpret_cast<float4*>(&hs[r * AHLD + 4 * c4]) = v;
-    }
-    __syncthreads();
-    // ---- in_proj: [128 x 64] . W_in^T [64 x 192]; wave w (of 8) owns row tile w ---------------------
+    // ---- in_proj: [64 x 64] . W_in^T [64 x 192]; wave w owns row tile w.  Split-bf16 product (six cross
+    // terms, fp32 accumulate) from prepared weight fragments; the 16 h rows are split here, once per wave.
+    const u32x4* aprep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]) + (int64_t)FFN_PAIRS * (FFN_FRAGS * 64) + lane;
     {
-        float af[16];
+        u32x4 xh[2], xm[2], xl[2];
         {
-            const float4* p = reinterpret_cast<const float4*>(&hs[(16 * w + jl) * AHLD + 16 * q]);
+            const bool ok = 16 * w + jl < rows;
+            const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + (ok ? 16 * w + jl : 0)) * E + 8 * q);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float4 v = p[c]; af[4 * c] = v.x; af[4 * c + 1] = v.y; af[4 * c + 2] = v.z; af[4 * c + 3] = v.w; }
+            for (int c = 0; c < 2; ++c) {
+                const float4 z = make_float4(0, 0, 0, 0);
+                split8(ok ? p[8 * c] : z, ok ? p[8 * c + 1] : z, xh[c], xm[c], xl[c]);
+            }
         }
-        float4 wn[4];
-        {
-            const float4* p = reinterpret_cast<const float4*>(W.inw + (int64_t)jl * E + 16 * q);
+        u32x4 wn[6];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) wn[c] = p[c];
-        }
+        for (int f = 0; f < 6; ++f) wn[f] = aprep[f * 64];
         for (int nt = 0; nt < 12; ++nt) {
-            float bf[16];
+            u32x4 wc[6];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { const float4 v = wn[c]; bf[4 * c] = v.x; bf[4 * c + 1] = v.y; bf[4 * c + 2] = v.z; bf[4 * c + 3] = v.w; }
-            if (nt + 1 < 12) {                                      // next tile's weight fragment in flight
-                const float4* p = reinterpret_cast<const float4*>(W.inw + (int64_t)(16 * (nt + 1) + jl) * E + 16 * q);
+            for (int f = 0; f < 6; ++f) wc[f] = wn[f];
+            if (nt + 1 < 12) {                                      // next tile's weight fragments in flight
 #pragma unroll
-                for (int c = 0; c < 4; ++c) wn[c] = p[c];
+                for (int f = 0; f < 6; ++f) wn[f] = aprep[((nt + 1) * 6 + f) * 64];
             }
             f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) { acc0 = mfma16(af[e], bf[e], acc0); acc1 = mfma16(af[e + 1], bf[e + 1], acc1); }
+            TF_MM6(acc0, xh[0], xm[0], xl[0], wc[0], wc[1], wc[2])
+            TF_MM6(acc1, xh[1], xm[1], xl[1], wc[3], wc[4], wc[5])
             const float bias = W.inb[16 * nt + jl];
             const float sc = nt < 4 ? 0.25f : 1.0f;                  // q / sqrt(head_dim)
 #pragma unroll
@@ -123,10 +126,19 @@ __global__ __launch_bounds__(512) void tf_attn_kernel(TfArgs a, int layer) {
             }
         }
     }
+    // the residual rows start their trip before the attention phase
+    float res[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + 4 * q + r;
+            res[c][r] = row < rows ? hin[(tok0 + row) * E + 16 * c + jl] : 0.0f;
+        }
     __syncthreads();
     // ---- attention: one wave per (sample, head) ------------------------------------------------
     const int nt16 = (S + 15) >> 4;                                 // key / query tiles per sample (1 or 2)
-    for (int p = w; p < ns * 4; p += 8) {
+    for (int p = w; p < ns * 4; p += 4) {
         const int si = p >> 2, hh = p & 3, rb = si * S;
         for (int qt = 0; qt < nt16; ++qt) {
             const int qrow = min(rb + 16 * qt + jl, AROWS - 1);
@@ -184,27 +196,38 @@ __global__ __launch_bounds__(512) void tf_attn_kernel(TfArgs a, int layer) {
     // ---- out_proj + residual + LayerNorm1 --------------------------------------------------------
     {
         const int rbase = 16 * w;
-        const float4* p = reinterpret_cast<const float4*>(&qkv[(rbase + jl) * QLD + 16 * q]);
-        float af[16];
+        // A operand: the context row rbase + jl, 8 consecutive columns per K chunk, split here
+        u32x4 xh[2], xm[2], xl[2];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 v = p[c]; af[4 * c] = v.x; af[4 * c + 1] = v.y; af[4 * c + 2] = v.z; af[4 * c + 3] = v.w;
-            if (Bf.ctx && rbase + jl < rows) reinterpret_cast<float4*>(Bf.ctx + (tok0 + rbase + jl) * E + 16 * q)[c] = v;
+        for (int c = 0; c < 2; ++c) {
+            const float4* p = reinterpret_cast<const float4*>(&qkv[(rbase + jl) * QLD + 32 * c + 8 * q]);
+            const float4 v0 = p[0], v1 = p[1];
+            split8(v0, v1, xh[c], xm[c], xl[c]);
+            if (Bf.ctx && rbase + jl < rows) {
+                float4* dst = reinterpret_cast<float4*>(Bf.ctx + (tok0 + rbase + jl) * E + 32 * c + 8 * q);
+                dst[0] = v0; dst[1] = v1;
+            }
         }
+        const u32x4* oprep = aprep + 72 * 64;
+        u32x4 wn[6];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) wn[f] = oprep[f * 64];
         float x[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float4* wp = reinterpret_cast<const float4*>(W.ow + (int64_t)(16 * c + jl) * E + 16 * q);
-            f32x4 acc = {0, 0, 0, 0};
+            u32x4 wc[6];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = wp[g];
-                acc = mfma16(af[4 * g], v.x, acc); acc = mfma16(af[4 * g + 1], v.y, acc);
-                acc = mfma16(af[4 * g + 2], v.z, acc); acc = mfma16(af[4 * g + 3], v.w, acc);
+            for (int f = 0; f < 6; ++f) wc[f] = wn[f];
+            if (c + 1 < 4) {
+#pragma unroll
+                for (int f = 0; f < 6; ++f) wn[f] = oprep[((c + 1) * 6 + f) * 64];
             }
+            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            TF_MM6(acc0, xh[0], xm[0], xl[0], wc[0], wc[1], wc[2])
+            TF_MM6(acc1, xh[1], xm[1], xl[1], wc[3], wc[4], wc[5])
             const float bias = W.ob[16 * c + jl];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[c][r] = (acc[r] + bias) + hs[(rbase + 4 * q + r) * AHLD + 16 * c + jl];
+            for (int r = 0; r < 4; ++r) x[c][r] = ((acc0[r] + acc1[r]) + bias) + res[c][r];
         }
         ln_rows(x, W.n1w, W.n1b, jl, q, Bf.x1 ? Bf.x1 + (tok0 + rbase) * E : nullptr,
                 Bf.x1 ? Bf.st1 + (tok0 + rbase) * 2 : nullptr, rows - rbase);
@@ -231,14 +254,9 @@ __global__ __launch_bounds__(512) void tf_attn_kernel(TfArgs a, int layer) {
 // (six cross terms, fp32 accumulate: DESIGN.md section 3): h is split once per wave, the weights once per
 // parameter change (tf_prepare_kernel), u after the ReLU.  The pair's 24 weight fragments (24 KB) are
 // fetched once per workgroup into double-buffered LDS and shared by its four waves.
-constexpr int FFN_FRAGS = 24, FFN_PAIRS = FF / 32;
 #ifndef MCTSQ_FFN_NT
 #define MCTSQ_FFN_NT 1      // token tiles of 16 per wave: 1 -> 16 waves (four per SIMD) per 256-token workgroup; measured 4.01 ms (1), 4.12 (2), 4.73 (4) per 16384-leaf forward
 #endif
-
-#define TF_MM6(ACC, XH, XM, XL, YH, YM, YL)                                              \
-    ACC = mfma_bf(XL, YH, ACC); ACC = mfma_bf(XH, YL, ACC); ACC = mfma_bf(XM, YM, ACC);   \
-    ACC = mfma_bf(XM, YH, ACC); ACC = mfma_bf(XH, YM, ACC); ACC = mfma_bf(XH, YH, ACC);
 
 template <int NT>
 __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int layer) {
@@ -370,12 +388,24 @@ __global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) {
 // FFN weights -> split-bf16 fragments: one thread per (pair, fragment group, lane); fragment order as
 // read by tf_ffn_kernel: W1 [unit tile m 2][K chunk c 2][plane 3], then W2 [out tile n 4][plane 3].
 __global__ __launch_bounds__(256) void tf_prepare_kernel(const float* __restrict__ l1w, const float* __restrict__ l2w,
+                                                        const float* __restrict__ inw, const float* __restrict__ ow,
                                                         u32x4* __restrict__ out) {
-    const int gid = blockIdx.x * 256 + threadIdx.x;           // FFN_PAIRS * 8 * 64 threads
+    const int gid = blockIdx.x * 256 + threadIdx.x;           // FFN_PAIRS * 8 * 64 threads, then 32 * 64 for the attention block
     const int lane = gid & 63, grp = (gid >> 6) & 7, pr = gid >> 9;
     const int jl = lane & 15, q = lane >> 4;
     float4 v0, v1;
     int f0;
+    if (gid >= FFN_PAIRS * 8 * 64) {                          // in_proj / out_proj: (column tile, K chunk) per 64 lanes
+        const int g2 = (gid - FFN_PAIRS * 8 * 64) >> 6;       // 0..23 in_proj, 24..31 out_proj
+        const float* w = g2 < 24 ? inw : ow;
+        const int g = g2 < 24 ? g2 : g2 - 24, tile = g >> 1, c = g & 1;
+        const float4* p = reinterpret_cast<const float4*>(w + (int64_t)(16 * tile + jl) * E + 32 * c + 8 * q);
+        u32x4 hi, mid, lo;
+        split8(p[0], p[1], hi, mid, lo);
+        u32x4* o = out + (int64_t)FFN_PAIRS * (FFN_FRAGS * 64) + lane;
+        o[(g2 * 3 + 0) * 64] = hi; o[(g2 * 3 + 1) * 64] = mid; o[(g2 * 3 + 2) * 64] = lo;
+        return;
+    }
     if (grp < 4) {                                            // W1: unit tile m, K chunk c
         const int m = grp >> 1, c = grp & 1;
         const float4* p = reinterpret_cast<const float4*>(l1w + (int64_t)(32 * pr + 16 * m + jl) * E + 32 * c + 8 * q);
@@ -393,8 +423,8 @@ __global__ __launch_bounds__(256) void tf_prepare_kernel(const float* __restrict
     o[(f0 + 0) * 64] = hi; o[(f0 + 1) * 64] = mid; o[(f0 + 2) * 64] = lo;
 }
 
-int launch_tf_prepare(const float* l1w, const float* l2w, void* prep, hipStream_t st) {
-    hipLaunchKernelGGL(tf_prepare_kernel, dim3(FFN_PAIRS * 8 * 64 / 256), dim3(256), 0, st, l1w, l2w,
+int launch_tf_prepare(const float* l1w, const float* l2w, const float* inw, const float* ow, void* prep, hipStream_t st) {
+    hipLaunchKernelGGL(tf_prepare_kernel, dim3((FFN_PAIRS * 8 + 32) * 64 / 256), dim3(256), 0, st, l1w, l2w, inw, ow,
                        reinterpret_cast<u32x4*>(prep));
     MCTSQ_HIP(hipGetLastError());
     return 0;
@@ -411,7 +441,7 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp * E / 256)), dim3(256), 0, st, a);
     const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / TOK_PER_WG);
     for (int l = 0; l < 2; ++l) {
-        hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(512), 0, st, a, l);
+        hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(256), 0, st, a, l);
         hipLaunchKernelGGL(tf_ffn_kernel<MCTSQ_FFN_NT>, dim3(ffn_grid), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st, a, l);
     }
     hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);

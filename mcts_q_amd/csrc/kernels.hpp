@@ -91,7 +91,7 @@ struct TfArgs {
     const float *pos, *ew, *eb;          // positional table [500][64], embedding Linear(F,64)
     TfLayerW layer[2];
     const float *lnw, *lnb;
-    int S, Fd, F, tf, out_col, NS;       // NS = whole samples per attention workgroup (NS*S <= 128)
+    int S, Fd, F, tf, out_col, NS;       // NS = whole samples per attention workgroup (NS*S <= 64)
     int64_t B, Bp, T, Tp;                // samples / tokens the block kernels process (training: B = Bp)
     int64_t Bvalid;                      // samples present in x (rows beyond are treated as zero windows)
     // token activations [Tp][64]: layer l reads hin, attention writes hmid, FFN writes hout.
@@ -100,14 +100,18 @@ struct TfArgs {
     float* feats;                        // [Bp][192]
     float* sv_mean;                      // training: [Bp][64] mean over time before the final LayerNorm
     float* sv_xe;                        // training: [Tp][8] embedded-input rows incl. time features
-    const void* ffn_prep[2];             // per layer: FFN weights as split-bf16 fragments (tf_prepare_kernel)
+    const void* ffn_prep[2];             // per layer: FFN, then in_proj / out_proj weights as split-bf16 fragments (tf_prepare_kernel)
 };
 int64_t tf_padded_tokens(int64_t B, int S);
 int launch_tf_fwd(const TfArgs& a, hipStream_t st);
 // FFN weights of one layer (linear1 [2048][64], linear2 [64][2048]) -> split-bf16 fragments in the
 // order tf_ffn_kernel consumes them: u32x4 [pair of hidden tiles 64][fragment 24][lane 64]
 constexpr int64_t TF_FFN_PREP_BYTES = 64 * 24 * 64 * 16;
-int launch_tf_prepare(const float* l1w, const float* l2w, void* prep, hipStream_t st);
+// ... followed by the attention block's in_proj [192][64] and out_proj [64][64] as split-bf16 B fragments:
+// u32x4 [in_proj column tile 12][K chunk 2][plane 3][lane 64], then [out_proj tile 4][K chunk 2][plane 3][lane 64]
+constexpr int64_t TF_ATTN_PREP_BYTES = (12 + 4) * 2 * 3 * 64 * 16;
+constexpr int64_t TF_LAYER_PREP_BYTES = TF_FFN_PREP_BYTES + TF_ATTN_PREP_BYTES;
+int launch_tf_prepare(const float* l1w, const float* l2w, const float* inw, const float* ow, void* prep, hipStream_t st);
 
 // ---------------- head ----------------
 struct HeadArgs {
