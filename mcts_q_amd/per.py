@@ -68,15 +68,31 @@ class DevicePER:
             lib.check(lib.mctsq_per_refresh_max(ptr(self.prio), self.capacity, self.head, self.size,
                                                 ptr(self.maxprio), ptr(ws), ws.numel(), self._st()))
             self._max_dirty = False
-        slots = (torch.arange(K, device=d) + (self.head + self.size)) % self.capacity
-        rows = torch.as_tensor(rows, dtype=torch.float32, device=d)
-        next_rows = torch.as_tensor(next_rows, dtype=torch.float32, device=d)
-        w = rows.shape[1]
-        self.states[slots, :w] = rows
-        self.next_states[slots, :w] = next_rows
-        self.actions[slots] = torch.as_tensor(actions, device=d).to(torch.int32)
-        self.rewards[slots] = torch.as_tensor(rewards, device=d).to(torch.float32)
-        self.dones[slots] = torch.as_tensor(dones, device=d).to(torch.float32)
+        # The K new slots are one contiguous run of the ring (two when it wraps): slice copies, no index kernels.
+        # Host inputs: the two row blocks as they are, the three small vectors as one [3, K] fp32 array (actions are
+        # small integers, exact in fp32).
+        start = (self.head + self.size) % self.capacity
+        n1 = min(K, self.capacity - start)
+        w = int(rows.shape[1])
+        host = not any(torch.is_tensor(t) for t in (rows, actions, rewards, next_rows, dones))
+        if host:
+            small = np.empty((3, K), dtype=np.float32)
+            small[0] = actions; small[1] = rewards; small[2] = dones
+            sm = torch.from_numpy(small).to(d)
+            rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(d)
+            next_rows = torch.from_numpy(np.ascontiguousarray(next_rows, dtype=np.float32)).to(d)
+            actions, rewards, dones = sm[0].to(torch.int32), sm[1], sm[2]
+        else:
+            rows = torch.as_tensor(rows, dtype=torch.float32, device=d)
+            next_rows = torch.as_tensor(next_rows, dtype=torch.float32, device=d)
+            actions = torch.as_tensor(actions, device=d).to(torch.int32)
+            rewards = torch.as_tensor(rewards, device=d).to(torch.float32)
+            dones = torch.as_tensor(dones, device=d).to(torch.float32)
+        for dst, src in ((self.states[:, :w], rows), (self.next_states[:, :w], next_rows), (self.actions, actions),
+                         (self.rewards, rewards), (self.dones, dones)):
+            dst[start:start + n1] = src[:n1]
+            if n1 < K:
+                dst[:K - n1] = src[n1:]
         lib.check(lib.mctsq_per_push(ptr(self.tree), ptr(self.prio), ptr(self.maxprio), self.capacity,
                                      self.head, self.size, K, self.alpha, self.mass_capacity, self._st()))
         over = max(0, self.size + K - self.capacity)
