@@ -346,8 +346,11 @@ struct GruWave {
             L.hb[1][nxt][i * HLD + j] = (unsigned short)(u1 >> 16);
             L.hb[2][nxt][i * HLD + j] = (unsigned short)(u2 >> 16);
             if (SAVE) {
-                const int64_t o = ((int64_t)t * Bp + row0 + i) * E + j;
-                s.sv_r[o] = rg[r]; s.sv_z[o] = zg[r]; s.sv_n[o] = ng; s.sv_hn[o] = hn; s.sv_h[o + Bp * E] = hnew;
+                // uniform 64-bit base (scalar registers) + 32-bit lane offset + constant: no vector address math
+                const int64_t ub = ((int64_t)t * Bp + row0) * E;
+                const int lo = (4 * q + r) * E + j;
+                (s.sv_r + ub)[lo] = rg[r]; (s.sv_z + ub)[lo] = zg[r]; (s.sv_n + ub)[lo] = ng; (s.sv_hn + ub)[lo] = hn;
+                (s.sv_h + ub + Bp * E)[lo] = hnew;
             }
             hh[cur][r] = hnew;
         }

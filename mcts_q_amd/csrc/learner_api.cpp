@@ -239,6 +239,9 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     {
         MCTSQ_HIP(hipEventRecord(side->fork, st));
         MCTSQ_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+        // the flat gradient's alignment pads must read zero; nothing touches it before the ordered reduction (step 7,
+        // behind the join), so the fill rides on the helper stream instead of the critical path
+        MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
         const float* x[3] = {d_nprice, d_nprocess, d_ngas};
         HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
         if (forward_impl(L, d_target_params, nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, side->st, nullptr))
@@ -413,7 +416,6 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
             return -1;
     }
     MCTSQ_CHECK(jb.part_pos <= P.partial_floats, "internal: partial buffer plan mismatch");
-    MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), st));     // alignment pads stay zero
     if (launch_gru_wgrad(gw, st)) return -1;
     for (int i = 0; i < jb.nlists; ++i)
         if (launch_wgrad(jb.lists[i], ws, ws + P.partials, st)) return -1;
