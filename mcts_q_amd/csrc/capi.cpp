@@ -39,8 +39,8 @@ void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, cons
         }
 }
 
-void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                    int64_t Bp, float* feats, const SlotSave* sv) {
+void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const void* prep,
+                    const float* const x[3], int64_t B, int64_t Bp, float* feats, const SlotSave* sv) {
     memset(&ca, 0, sizeof(ca));
     ca.B = B; ca.Bp = Bp; ca.feats = feats;
     for (int s = 0; s < 2; ++s) {
@@ -51,6 +51,7 @@ void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, co
         c.w1 = params + e.conv.w1; c.b1 = params + e.conv.b1; c.w2 = params + e.conv.w2; c.b2 = params + e.conv.b2;
         c.aw = params + e.conv.aw; c.ab = params + e.conv.ab; c.lnw = params + e.conv.lnw; c.lnb = params + e.conv.lnb;
         c.S = e.S; c.Fd = e.Fd; c.F = e.F; c.tf = e.tf; c.out_col = s * E;
+        c.wprep = prep ? (const char*)prep + gru_prepared_bytes(L) + (ca.nslots - 1) * CONV_PREP_BYTES : nullptr;
         if (sv) {
             const SlotSave& v = sv[s];
             c.sv_h1 = v.c_h1; c.sv_h2 = v.c_h2; c.sv_score = v.score; c.sv_stat = v.stat; c.sv_pool = v.pool;
@@ -78,12 +79,17 @@ int64_t forward_ws_floats(const NetLayout& L, int64_t Bp) {
     return n + prepared_bytes(L) / (int64_t)sizeof(float);
 }
 
-// layout of the prepared buffer: the GRU slots' fragments first (slot order), then 2 layers per
-// transformer slot
-static int64_t gru_prepared_bytes(const NetLayout& L) {
+// layout of the prepared buffer: the GRU slots' fragments first (slot order), then the conv slots', then 2 layers
+// per transformer slot
+int64_t gru_prepared_bytes(const NetLayout& L) {
     int n = 0;
     for (int s = 0; s < 3; ++s) n += L.enc[s].kind == MCTSQ_ENC_GRU;
     return n * GRU_PREP_BYTES;
+}
+static int64_t conv_prepared_bytes(const NetLayout& L) {
+    int n = 0;
+    for (int s = 0; s < 2; ++s) n += L.enc[s].kind == MCTSQ_ENC_CONV;
+    return n * CONV_PREP_BYTES;
 }
 static int64_t tf_prepared_bytes(const NetLayout& L) {
     int n = 0;
@@ -99,7 +105,7 @@ static bool fused_layout(const NetLayout& L) {
 }
 // ... then the head's fragments when the fused kernel serves the network
 int64_t prepared_bytes(const NetLayout& L) {
-    return gru_prepared_bytes(L) + tf_prepared_bytes(L) + (fused_layout(L) ? HEAD_PREP_BYTES : 0);
+    return gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L) + (fused_layout(L) ? HEAD_PREP_BYTES : 0);
 }
 
 int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_t st) {
@@ -109,6 +115,14 @@ int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_
         if (L.enc[s].kind == MCTSQ_ENC_GRU) whh[n++] = params + L.enc[s].gru.whh;
     if (launch_gru_prepare(whh, n, prep, st)) return -1;
     char* p = (char*)prep + gru_prepared_bytes(L);
+    {
+        const float* w2[2] = {nullptr, nullptr};
+        int nc = 0;
+        for (int s = 0; s < 2; ++s)
+            if (L.enc[s].kind == MCTSQ_ENC_CONV) w2[nc++] = params + L.enc[s].conv.w2;
+        if (launch_conv_prepare(w2, nc, p, st)) return -1;
+        p += conv_prepared_bytes(L);
+    }
     for (int s = 0; s < 3; ++s) {
         if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
         for (int l = 0; l < 2; ++l) {
@@ -162,7 +176,7 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     GruFwdArgs ga;
     fill_gru_args(ga, L, params, prep, x, B, Bp, feats, sv);
     ConvFwdArgs ca;
-    fill_conv_args(ca, L, params, x, B, Bp, feats, sv);
+    fill_conv_args(ca, L, params, prep, x, B, Bp, feats, sv);
     MlpArgs ma;
     const bool has_mlp = fill_mlp_args(ma, L, params, x, B, Bp, feats, sv);
     const bool has_tf = L.enc[0].kind == MCTSQ_ENC_TRANSFORMER || L.enc[1].kind == MCTSQ_ENC_TRANSFORMER;
@@ -178,7 +192,7 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     const bool save = sv != nullptr;
     if (save)
         for (int i = 0; i + 1 < L.n_fc; ++i) ha.sv_act[i] = sv_act[i];
-    if (fused_layout(L)) ha.wprep = (const char*)prep + gru_prepared_bytes(L) + tf_prepared_bytes(L);
+    if (fused_layout(L)) ha.wprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L);
 
     if (fused_gru_head_applicable(ga, ha)) {                 // shipped default: one launch
         if (!save) ga.feats = nullptr;                       // training keeps the feature rows for the head backward
@@ -188,7 +202,7 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     }
     {
         float* hbuf = ws + Bp * FEAT;
-        const char* tprep = (const char*)prep + gru_prepared_bytes(L);
+        const char* tprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L);
         for (int s = 0; s < 2; ++s) {
             if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
             TfArgs t;

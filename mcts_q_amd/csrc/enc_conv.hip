@@ -61,11 +61,15 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
         const int k = 4 * kk + q, tap = k / FP, f = k - tap * FP;
         w1f[kk] = (kk < nk1 && f < F) ? s.w1[(int64_t)j * F * 3 + f * 3 + tap] : 0.0f;
     }
-    float w2f[3][16];
+    // conv2 weights: prepared split-bf16 B fragments, chunk = 2 tap + half (32 input channels each)
+    u32x4 w2p[6][3];
+    {
+        const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep) + (int64_t)wq * (6 * 3 * 64) + lane;
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
+        for (int c = 0; c < 6; ++c)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) w2f[tap][e] = s.w2[(int64_t)j * (E * 3) + (16 * q + e) * 3 + tap];
+            for (int pl = 0; pl < 3; ++pl) w2p[c][pl] = wp[(c * 3 + pl) * 64];
+    }
     const float b1j = s.b1[j], b2j = s.b2[j];
     PoolCore<SAVE> pc;
     pc.init(s.aw, s.ab, lane, wq);
@@ -88,20 +92,25 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
     __syncthreads();
 
     // ---- conv2 + ReLU, attention pooling folded online ---------------------------------------------
-    for (int t = 0; t < S; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-        const float4* r0 = reinterpret_cast<const float4*>(&L.img[((t + 0) * TILE + (lane & 15)) * CLD + 16 * q]);
-        const float4* r1 = reinterpret_cast<const float4*>(&L.img[((t + 1) * TILE + (lane & 15)) * CLD + 16 * q]);
-        const float4* r2 = reinterpret_cast<const float4*>(&L.img[((t + 2) * TILE + (lane & 15)) * CLD + 16 * q]);
+    // [16 x 192] . [192 x 64] per step on the bf16 matrix instruction over the exact three-way split of both
+    // operands (six cross terms, fp32 accumulate: DESIGN.md section 3).  The A operand of step t is the image
+    // rows t, t+1, t+2 (taps 0, 1, 2); every row is read from LDS and split ONCE and then serves three steps from
+    // registers (three fragment sets rotate; the loop is unrolled by three so they never move).
+    struct RowFrag { u32x4 h[2], m[2], l[2]; };
+    auto load_row = [&](int tp, RowFrag& f) {
+        const float4* p = reinterpret_cast<const float4*>(&L.img[(tp * TILE + (lane & 15)) * CLD + 8 * q]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 a0 = r0[c], a1 = r1[c], a2 = r2[c];
-            acc0 = mfma16(a0.x, w2f[0][4 * c + 0], acc0); acc1 = mfma16(a1.x, w2f[1][4 * c + 0], acc1); acc2 = mfma16(a2.x, w2f[2][4 * c + 0], acc2);
-            acc0 = mfma16(a0.y, w2f[0][4 * c + 1], acc0); acc1 = mfma16(a1.y, w2f[1][4 * c + 1], acc1); acc2 = mfma16(a2.y, w2f[2][4 * c + 1], acc2);
-            acc0 = mfma16(a0.z, w2f[0][4 * c + 2], acc0); acc1 = mfma16(a1.z, w2f[1][4 * c + 2], acc1); acc2 = mfma16(a2.z, w2f[2][4 * c + 2], acc2);
-            acc0 = mfma16(a0.w, w2f[0][4 * c + 3], acc0); acc1 = mfma16(a1.w, w2f[1][4 * c + 3], acc1); acc2 = mfma16(a2.w, w2f[2][4 * c + 3], acc2);
-        }
+        for (int hf = 0; hf < 2; ++hf) split8(p[8 * hf], p[8 * hf + 1], f.h[hf], f.m[hf], f.l[hf]);
+    };
+#define CONV_MM6(ACC, F, HF, W)                                                                           \
+    ACC = mfma_bf(F.l[HF], (W)[0], ACC); ACC = mfma_bf(F.h[HF], (W)[2], ACC); ACC = mfma_bf(F.m[HF], (W)[1], ACC); \
+    ACC = mfma_bf(F.m[HF], (W)[0], ACC); ACC = mfma_bf(F.h[HF], (W)[1], ACC); ACC = mfma_bf(F.h[HF], (W)[0], ACC);
+    auto step = [&](int t, RowFrag& ra, RowFrag& rb, RowFrag& rc) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        load_row(t + 2, rc);
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        CONV_MM6(acc0, ra, 0, w2p[0]) CONV_MM6(acc1, rb, 0, w2p[2]) CONV_MM6(acc2, rc, 0, w2p[4])
+        CONV_MM6(acc0, ra, 1, w2p[1]) CONV_MM6(acc1, rb, 1, w2p[3]) CONV_MM6(acc2, rc, 1, w2p[5])
         if (t > 0) pc.attend(L.pool, cur, t - 1, s.sv_score, row0, Bp);
         float v[4];
 #pragma unroll
@@ -111,7 +120,18 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
         }
         pc.publish(L.pool, nxt, v);
         __syncthreads();
+    };
+    {
+        RowFrag f0, f1, f2;
+        load_row(0, f0);
+        load_row(1, f1);
+        for (int t = 0; t < S; t += 3) {
+            step(t, f0, f1, f2);
+            if (t + 1 < S) step(t + 1, f1, f2, f0);
+            if (t + 2 < S) step(t + 2, f2, f0, f1);
+        }
     }
+#undef CONV_MM6
     pc.attend(L.pool, S & 1, S - 1, s.sv_score, row0, Bp);
     pc.fin0(L.pool);
     __syncthreads();
@@ -120,9 +140,36 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
     pc.fin2(L.pool, s.lnw, s.lnb, args.feats + row0 * FEAT + s.out_col, FEAT, s.sv_pool, s.sv_stat, row0);
 }
 
+// one thread per (slot, wave, chunk, lane): 8 input channels of one tap -> 3 x 8 bf16
+struct ConvPrepArgs { const float* w2[2]; u32x4* out; };
+__global__ __launch_bounds__(256) void conv_prepare_kernel(ConvPrepArgs a) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;           // grid = n * 6 blocks of 256
+    const int lane = tid & 63, rest = tid >> 6, c = rest % 6, wq = (rest / 6) & 3, slot = rest / 24;
+    const int jl = lane & 15, q = lane >> 4, tap = c >> 1, cin0 = 32 * (c & 1) + 8 * q;
+    const float* w = a.w2[slot] + (int64_t)(16 * wq + jl) * (E * 3) + tap;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[(cin0 + e) * 3];
+    u32x4 hi, mid, lo;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, mid, lo);
+    u32x4* o = a.out + (int64_t)slot * (CONV_PREP_BYTES / 16) + ((wq * 6 + c) * 3) * 64 + lane;
+    o[0] = hi; o[64] = mid; o[128] = lo;
+}
+int launch_conv_prepare(const float* const w2[2], int n, void* prep, hipStream_t st) {
+    if (n == 0) return 0;
+    ConvPrepArgs a;
+    for (int i = 0; i < 2; ++i) a.w2[i] = w2[i < n ? i : 0];
+    a.out = reinterpret_cast<u32x4*>(prep);
+    hipLaunchKernelGGL(conv_prepare_kernel, dim3((unsigned)(n * 6)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_conv_fwd(const ConvFwdArgs& a, bool save, hipStream_t st) {
     if (a.nslots == 0 || a.B == 0) return 0;
     int smax = 0;
+    for (int i = 0; i < a.nslots; ++i)
+        MCTSQ_CHECK(a.slot[i].wprep && ((uintptr_t)a.slot[i].wprep & 15) == 0, "conv encoder needs prepared weights");
     for (int i = 0; i < a.nslots; ++i) {
         MCTSQ_CHECK(a.slot[i].S <= 26 && a.slot[i].F <= MAX_F, "conv encoder window %dx%d unsupported (S <= 26)",
                     a.slot[i].S, a.slot[i].F);

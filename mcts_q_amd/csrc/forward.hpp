@@ -29,8 +29,9 @@ struct HeadOut {
 
 void fill_gru_args(GruFwdArgs& ga, const NetLayout& L, const float* params, const void* prep,
                    const float* const x[3], int64_t B, int64_t Bp, float* feats, const SlotSave* sv);
-void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
-                    int64_t Bp, float* feats, const SlotSave* sv);
+int64_t gru_prepared_bytes(const NetLayout& L);
+void fill_conv_args(ConvFwdArgs& ca, const NetLayout& L, const float* params, const void* prep,
+                    const float* const x[3], int64_t B, int64_t Bp, float* feats, const SlotSave* sv);
 bool fill_mlp_args(MlpArgs& ma, const NetLayout& L, const float* params, const float* const x[3], int64_t B,
                    int64_t Bp, float* feats, const SlotSave* sv);
 // floats of forward scratch: feature rows [Bp][192] + token buffers of the transformer slots + the

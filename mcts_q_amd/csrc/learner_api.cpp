@@ -304,7 +304,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     // 5. encoder backward (deltas)
     {
         ConvFwdArgs ca;
-        fill_conv_args(ca, L, d_params, xs, B, Bp, ws + P.feats_p, sv);
+        fill_conv_args(ca, L, d_params, nullptr, xs, B, Bp, ws + P.feats_p, sv);
         ConvBwdArgs cb;
         memset(&cb, 0, sizeof(cb));
         cb.nslots = ca.nslots; cb.Bp = Bp; cb.dfeat = ws + P.dfeat;
