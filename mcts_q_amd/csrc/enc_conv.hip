@@ -1,9 +1,10 @@
 // ConvAttentionEnc (dqn_per.py:21-55) forward and backward.
 //
 // One workgroup (4 waves) = one 16-sample tile of one conv slot.  Rows of every product are the 16
-// samples at ONE time step, so a k=3 convolution is three row-shifted reads of the LDS image
-// [t+1][sample][channel] (zero rows at t = -1 and t = S): conv2 is [16 x 192].[192 x 64] per step
-// on v_mfma_f32_16x16x4_f32 with the wave's 16 output channels of W2 resident in 48 VGPRs.
+// samples at ONE time step, so a k=3 convolution multiplies three consecutive rows [sample][channel] of
+// the previous layer (zero rows at t = -1 and t = S): conv2 is [16 x 192].[192 x 64] per step.  The forward
+// runs it on the bf16 matrix instruction (exact three-way split, prepared weight fragments resident in 72
+// VGPRs) and keeps only two h1 rows in LDS; the backward works on a full LDS image with fp32 MFMA.
 // The softmax over time is folded online (one barrier per step), then LayerNorm.
 #include "kernels.hpp"
 #include "learner.hpp"
@@ -21,10 +22,22 @@ struct ConvLds {
     PoolBwdLds pb;
 };
 
-template <bool SAVE, int SMAX>
-__global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
-    __shared__ __attribute__((aligned(16))) ConvLds<SMAX> L;
-    constexpr int XLD = (SMAX + 2) * 8 + 4;
+constexpr int CONV_SMAX = 26;
+constexpr int CXLD = (CONV_SMAX + 2) * 8 + 4;
+struct ConvFwdLds {
+    float row[2][TILE * CLD];   // h1 rows in flight: row tp lives in slot tp & 1, written one step before it is read
+    float xs[TILE * CXLD];
+    PoolLds pool;
+};
+
+// Forward.  h1 never exists as a whole image: at step t every wave computes its 16 channels of row t+3 (conv1 is
+// 3-6 fp32 MFMAs) into a two-slot LDS buffer, reads row t+2 ONCE, splits it into bf16 planes in registers, and
+// multiplies rows t, t+1, t+2 (taps 0, 1, 2 of conv2) from three rotating register sets.  25 KB of LDS and
+// ~200 VGPRs let two workgroups (e.g. the price and the process window of one tile) share a CU.
+template <bool SAVE>
+__global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) {
+    __shared__ __attribute__((aligned(16))) ConvFwdLds L;
+    constexpr int XLD = CXLD;
     const int slot = blockIdx.x % args.nslots;
     const int64_t row0 = (int64_t)(blockIdx.x / args.nslots) * TILE, Bp = args.Bp;
     const ConvSlot& s = args.slot[slot];
@@ -32,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
     const int j = 16 * wq + jl;
     const int S = s.S, F = s.F, Fd = s.Fd, FP = F > 4 ? 8 : 4;
 
-    // ---- stage the window (zero rows at both ends) and zero the pad rows of the h1 image ----
+    // ---- stage the window (zero rows at both ends) ---------------------------------------------
     for (int idx = tid; idx < TILE * (S + 2) * FP; idx += 256) {
         const int i = idx / ((S + 2) * FP), rem = idx - i * ((S + 2) * FP), tp = rem / FP, f = rem - tp * FP;
         const int t = tp - 1;
@@ -47,12 +60,12 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
             const int i = idx / ((S + 2) * 4), rem = idx - i * ((S + 2) * 4);
             s.sv_x[((int64_t)(rem >> 2) * Bp + row0 + i) * 8 + 4 + (rem & 3)] = 0.0f;
         }
-    for (int idx = tid; idx < 2 * TILE * E; idx += 256) {
-        const int e = idx & (TILE * E - 1), i = e >> 6, c = e & 63;
-        const int tp = idx < TILE * E ? 0 : S + 1;
-        L.img[(tp * TILE + i) * CLD + c] = 0.0f;
-        if (SAVE) s.sv_h1[((int64_t)tp * Bp + row0 + i) * E + c] = 0.0f;
-    }
+    if (SAVE)                                                    // zero pad rows of the h1 record
+        for (int idx = tid; idx < 2 * TILE * E; idx += 256) {
+            const int e = idx & (TILE * E - 1), i = e >> 6, c = e & 63;
+            const int tp = idx < TILE * E ? 0 : S + 1;
+            s.sv_h1[((int64_t)tp * Bp + row0 + i) * E + c] = 0.0f;
+        }
     // ---- weight fragments ----------------------------------------------------------------------
     const int nk1 = 3 * FP / 4;                                  // 3 or 6 k-steps for conv1
     float w1f[6];
@@ -75,30 +88,29 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
     pc.init(s.aw, s.ab, lane, wq);
     __syncthreads();
 
-    // ---- conv1 + ReLU -> h1 image ----------------------------------------------------------------
-    for (int t = 0; t < S; ++t) {
-        const float* xa = &L.xs[(lane & 15) * XLD + t * FP + q];
+    // conv1 + ReLU for image row tp (1..S = time step tp-1; S+1 = the zero pad) -> LDS slot tp & 1
+    auto conv1_row = [&](int tp) {
         f32x4 acc = {0, 0, 0, 0};
+        const bool real = tp <= S;
+        if (real) {
+            const float* xa = &L.xs[(lane & 15) * XLD + (tp - 1) * FP + q];
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk)
-            if (kk < nk1) acc = mfma16(xa[4 * kk], w1f[kk], acc);
+            for (int kk = 0; kk < 6; ++kk)
+                if (kk < nk1) acc = mfma16(xa[4 * kk], w1f[kk], acc);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = fmaxf(acc[r] + b1j, 0.0f);
-            L.img[((t + 1) * TILE + 4 * q + r) * CLD + j] = v;
-            if (SAVE) s.sv_h1[((int64_t)(t + 1) * Bp + row0 + 4 * q + r) * E + j] = v;
+            const float v = real ? fmaxf(acc[r] + b1j, 0.0f) : 0.0f;
+            L.row[tp & 1][(4 * q + r) * CLD + j] = v;
+            if (SAVE && real) s.sv_h1[((int64_t)tp * Bp + row0 + 4 * q + r) * E + j] = v;
         }
-    }
-    __syncthreads();
-
+    };
     // ---- conv2 + ReLU, attention pooling folded online ---------------------------------------------
     // [16 x 192] . [192 x 64] per step on the bf16 matrix instruction over the exact three-way split of both
-    // operands (six cross terms, fp32 accumulate: DESIGN.md section 3).  The A operand of step t is the image
-    // rows t, t+1, t+2 (taps 0, 1, 2); every row is read from LDS and split ONCE and then serves three steps from
-    // registers (three fragment sets rotate; the loop is unrolled by three so they never move).
+    // operands (six cross terms, fp32 accumulate: DESIGN.md section 3).
     struct RowFrag { u32x4 h[2], m[2], l[2]; };
     auto load_row = [&](int tp, RowFrag& f) {
-        const float4* p = reinterpret_cast<const float4*>(&L.img[(tp * TILE + (lane & 15)) * CLD + 8 * q]);
+        const float4* p = reinterpret_cast<const float4*>(&L.row[tp & 1][(lane & 15) * CLD + 8 * q]);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) split8(p[8 * hf], p[8 * hf + 1], f.h[hf], f.m[hf], f.l[hf]);
     };
@@ -107,6 +119,7 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
     ACC = mfma_bf(F.m[HF], (W)[0], ACC); ACC = mfma_bf(F.h[HF], (W)[1], ACC); ACC = mfma_bf(F.h[HF], (W)[0], ACC);
     auto step = [&](int t, RowFrag& ra, RowFrag& rb, RowFrag& rc) {
         const int cur = t & 1, nxt = cur ^ 1;
+        if (t + 3 <= S + 1) conv1_row(t + 3);                    // for the next step, into the other slot
         load_row(t + 2, rc);
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
         CONV_MM6(acc0, ra, 0, w2p[0]) CONV_MM6(acc1, rb, 0, w2p[2]) CONV_MM6(acc2, rc, 0, w2p[4])
@@ -123,8 +136,14 @@ __global__ __launch_bounds__(256) void conv_enc_fwd_kernel(ConvFwdArgs args) {
     };
     {
         RowFrag f0, f1, f2;
-        load_row(0, f0);
+        const u32x4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) { f0.h[hf] = z; f0.m[hf] = z; f0.l[hf] = z; }   // row 0: the zero pad at t = -1
+        conv1_row(1);
+        __syncthreads();
         load_row(1, f1);
+        conv1_row(2);
+        __syncthreads();
         for (int t = 0; t < S; t += 3) {
             step(t, f0, f1, f2);
             if (t + 1 < S) step(t + 1, f1, f2, f0);
@@ -177,13 +196,9 @@ int launch_conv_fwd(const ConvFwdArgs& a, bool save, hipStream_t st) {
     }
     MCTSQ_CHECK(a.Bp % TILE == 0 && a.Bp >= a.B, "padded batch must be a multiple of %d", TILE);
     dim3 grid((unsigned)(a.Bp / TILE * a.nslots)), blk(256);
-    if (smax <= 12) {
-        if (save) hipLaunchKernelGGL((conv_enc_fwd_kernel<true, 12>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((conv_enc_fwd_kernel<false, 12>), grid, blk, 0, st, a);
-    } else {
-        if (save) hipLaunchKernelGGL((conv_enc_fwd_kernel<true, 26>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((conv_enc_fwd_kernel<false, 26>), grid, blk, 0, st, a);
-    }
+    (void)smax;
+    if (save) hipLaunchKernelGGL(conv_enc_fwd_kernel<true>, grid, blk, 0, st, a);
+    else hipLaunchKernelGGL(conv_enc_fwd_kernel<false>, grid, blk, 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
