@@ -96,16 +96,14 @@ static int64_t tf_prepared_bytes(const NetLayout& L) {
     for (int s = 0; s < 3; ++s) n += L.enc[s].kind == MCTSQ_ENC_TRANSFORMER;
     return 2 * n * TF_LAYER_PREP_BYTES;
 }
-// the network the fused GRU + head kernel serves (fused_gru_head_applicable, in terms of the layout)
-static bool fused_layout(const NetLayout& L) {
-    for (int s = 0; s < 3; ++s)
-        if (L.enc[s].kind != MCTSQ_ENC_GRU) return false;
+// the head shape the split-bf16 head serves (fused kernel and head_bf16_fwd_kernel; head_core.hpp)
+static bool head_bf16_layout(const NetLayout& L) {
     return L.n_fc == 3 && L.fc_in[0] == FEAT && L.fc_out[0] == 128 && L.fc_in[1] == 128 && L.fc_out[1] == 128 &&
            L.fc_in[2] == 128 && L.A <= 16;
 }
 // ... then the head's fragments when the fused kernel serves the network
 int64_t prepared_bytes(const NetLayout& L) {
-    return gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L) + (fused_layout(L) ? HEAD_PREP_BYTES : 0);
+    return gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L) + (head_bf16_layout(L) ? HEAD_PREP_BYTES : 0);
 }
 
 int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_t st) {
@@ -131,7 +129,7 @@ int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_
             p += TF_LAYER_PREP_BYTES;
         }
     }
-    if (fused_layout(L) &&
+    if (head_bf16_layout(L) &&
         launch_head_prepare(params + L.fc_w[0], params + L.fc_w[1], params + L.fc_w[2], L.A, p, st))
         return -1;
     return 0;
@@ -192,7 +190,7 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     const bool save = sv != nullptr;
     if (save)
         for (int i = 0; i + 1 < L.n_fc; ++i) ha.sv_act[i] = sv_act[i];
-    if (fused_layout(L)) ha.wprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L);
+    if (head_bf16_layout(L)) ha.wprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L);
 
     if (fused_gru_head_applicable(ga, ha)) {                 // shipped default: one launch
         if (!save) ga.feats = nullptr;                       // training keeps the feature rows for the head backward

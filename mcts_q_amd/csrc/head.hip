@@ -5,6 +5,7 @@
 // streamed from L2 (the whole head is 164 KB).
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "head_core.hpp"
 
 namespace mctsq {
 
@@ -135,6 +136,62 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
     }
 }
 
+// Head weights -> split-bf16 B fragments in the order the fused kernel loads them: lane (jl, q) of fragment
+// (tile, chunk c) holds W[16 tile + jl][32c + 8q .. +7]; rows >= A of the output layer are zero.
+__global__ __launch_bounds__(256) void head_prepare_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, int A, u32x4* __restrict__ out) {
+    const int tid = blockIdx.x * 256 + threadIdx.x, lane = tid & 63, fg = tid >> 6;
+    if (fg >= 48 + 32 + 4) return;
+    const int jl = lane & 15, q = lane >> 4;
+    const float* w;
+    int K, tile, c, base;
+    bool valid = true;
+    if (fg < 48) { w = w0; K = FEAT; tile = fg / 6; c = fg % 6; base = fg * 3; }
+    else if (fg < 80) { const int f = fg - 48; w = w1; K = 128; tile = f / 4; c = f % 4; base = H0_FR + f * 3; }
+    else { const int f = fg - 80; w = w2; K = 128; tile = 0; c = f; base = H0_FR + H1_FR + f * 3; valid = jl < A; }
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (valid) {
+        const float4* p = reinterpret_cast<const float4*>(w + (int64_t)(16 * tile + jl) * K + 32 * c + 8 * q);
+        a = p[0]; b = p[1];
+    }
+    u32x4 hi, mid, lo;
+    split8(a, b, hi, mid, lo);
+    out[(base + 0) * 64 + lane] = hi; out[(base + 1) * 64 + lane] = mid; out[(base + 2) * 64 + lane] = lo;
+}
+int launch_head_prepare(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st) {
+    MCTSQ_CHECK(w0 && w1 && w2 && prep && A >= 1 && A <= 16, "head prepare: bad arguments");
+    hipLaunchKernelGGL(head_prepare_kernel, dim3((84 * 64 + 255) / 256), dim3(256), 0, st, w0, w1, w2, A,
+                       reinterpret_cast<u32x4*>(prep));
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- the 192-128-128-A head on split-bf16 MFMA (head_core.hpp) for feature rows that are in global memory:
+// every encoder mix other than gru/gru/gru (whose fused kernel runs the same code on features still in LDS)
+template <bool SAVE>
+__global__ __launch_bounds__(512) void head_bf16_fwd_kernel(HeadArgs ha) {
+    __shared__ __attribute__((aligned(16))) HeadLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * TILE;
+    HeadWave<SAVE> hd;
+    hd.load(ha, lane, wave);
+    for (int idx = tid; idx < TILE * FEAT; idx += 512) {
+        const int i = idx / FEAT, c = idx - i * FEAT;
+        unsigned u0, u1, u2;
+        split3(ha.feats[(row0 + i) * (int64_t)FEAT + c], u0, u1, u2);
+        L.fpl[0][i * FPL + c] = (unsigned short)(u0 >> 16);
+        L.fpl[1][i * FPL + c] = (unsigned short)(u1 >> 16);
+        L.fpl[2][i * FPL + c] = (unsigned short)(u2 >> 16);
+    }
+    __syncthreads();
+    hd.run(ha, L, lane, wave, row0);
+}
+
+bool head_bf16_applicable(const HeadArgs& ha) {
+    return ha.wprep && ha.n_fc == 3 && ha.in[0] == FEAT && ha.out[0] == 128 && ha.in[1] == 128 && ha.out[1] == 128 &&
+           ha.in[2] == 128 && ha.A <= 16;
+}
+
 int launch_head_fwd(const HeadArgs& args, hipStream_t st) {
     if (args.B == 0) return 0;
     for (int l = 0; l < args.n_fc; ++l) {
@@ -143,6 +200,12 @@ int launch_head_fwd(const HeadArgs& args, hipStream_t st) {
     }
     const bool save = args.sv_act[0] != nullptr;
     dim3 grid((unsigned)(args.Bp / TILE));
+    if (head_bf16_applicable(args)) {
+        if (save) hipLaunchKernelGGL(head_bf16_fwd_kernel<true>, grid, dim3(512), 0, st, args);
+        else hipLaunchKernelGGL(head_bf16_fwd_kernel<false>, grid, dim3(512), 0, st, args);
+        MCTSQ_HIP(hipGetLastError());
+        return 0;
+    }
     if (save) hipLaunchKernelGGL(head_fwd_kernel<true>, grid, dim3(256), 0, st, args);
     else hipLaunchKernelGGL(head_fwd_kernel<false>, grid, dim3(256), 0, st, args);
     MCTSQ_HIP(hipGetLastError());
