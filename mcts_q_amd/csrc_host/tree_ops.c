@@ -1,0 +1,62 @@
+/* Host-side inner loops of the lock-step tree search (mcts_q_amd/treesearch.py): PUCT selection and value
+ * backup over K independent trees stored as flat arrays.  The serial tree logic stays on the host by design
+ * (north star); this file only takes the two per-iteration loops out of numpy and spreads the trees over the
+ * host cores.  Arithmetic and tie-breaking are those of the numpy path, which restates
+ * mctsq_config_mcts_per.py:266-308 (select) and :358-381 (backup); tests/test_treesearch_cpu.py runs both paths
+ * against each other.  Built by mcts_q_amd/csrc/Makefile into mcts_q_amd/lib/libmctsq_tree.so (gcc, no GPU code). */
+#include <math.h>
+#include <stdint.h>
+
+#define N_ACT 5
+
+/* cur_out[k] = the node selection stops at for tree k: a terminal node, a node at the depth limit, or the first
+ * node with an untried legal action. */
+void mctsq_tree_select(int64_t K, const int64_t* root, int64_t maxd, double c_base, double c_init,
+                       const uint8_t* done, const int64_t* depth, const int64_t* legal, const int64_t* tried,
+                       const int64_t* child, const int64_t* visits, const double* total, const double* prior_a,
+                       int64_t* cur_out) {
+#pragma omp parallel for schedule(static) if (K >= 256)
+    for (int64_t k = 0; k < K; ++k) {
+        int64_t cur = root[k];
+        for (;;) {
+            if (done[cur] || depth[cur] >= maxd || tried[cur] != legal[cur]) break;
+            const int64_t* ch = child + cur * N_ACT;
+            int64_t tv = 0;
+            for (int a = 0; a < N_ACT; ++a)
+                if (ch[a] >= 0) tv += visits[ch[a]];
+            const double c_puct = log((1.0 + (double)tv + c_base) / c_base) + c_init;   /* :273 */
+            const double sq = sqrt((double)tv);
+            double best = -INFINITY;
+            int64_t pick = -1;
+            for (int a = 0; a < N_ACT; ++a) {                 /* creation order, first maximum wins */
+                const int64_t c = ch[a];
+                if (c < 0) continue;
+                const int64_t v = visits[c];
+                const double vf = (double)v;
+                const double mean = v > 0 ? total[c] / vf : 0.0;
+                const double explore = c_puct * prior_a[c] * sq / (1.0 + vf);
+                const double score = mean + explore;
+                if (pick < 0 || score > best) { best = score; pick = c; }
+            }
+            if (pick < 0) break;                              /* no child: nothing to descend into */
+            cur = pick;
+        }
+        cur_out[k] = cur;
+    }
+}
+
+/* every node on the path leaf -> root of tree k gains one visit and the leaf's value */
+void mctsq_tree_backup(int64_t K, const int64_t* leaf, const double* vmax, const int64_t* parent, int64_t* visits,
+                       double* total) {
+#pragma omp parallel for schedule(static) if (K >= 256)
+    for (int64_t k = 0; k < K; ++k) {
+        int64_t node = leaf[k];
+        if (node < 0) continue;
+        const double value = vmax[node];
+        while (node >= 0) {
+            visits[node] += 1;
+            total[node] += value;
+            node = parent[node];
+        }
+    }
+}

@@ -23,6 +23,7 @@ returns the first maximum in that order (mcts_per.py:308, 553).
 from __future__ import annotations
 
 import math
+import os
 import random
 
 import numpy as np
@@ -44,6 +45,28 @@ def legal_mask(meth_state) -> int:
         return _LEGAL.get(int(meth_state), _ALL)
     except (TypeError, ValueError):
         return _ALL
+
+
+_TREE_LIB = None
+
+
+def _tree_lib():
+    """libmctsq_tree.so (mcts_q_amd/csrc_host/tree_ops.c): selection and backup over all trees in C, spread over
+    the host cores.  Raises if the library was not built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _TREE_LIB
+    if _TREE_LIB is None:
+        import ctypes
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmctsq_tree.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with make -C mcts_q_amd/csrc")
+        L = ctypes.CDLL(path)
+        P, I64, F64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double
+        L.mctsq_tree_select.argtypes = [I64, P, I64, F64, F64, P, P, P, P, P, P, P, P, P]
+        L.mctsq_tree_select.restype = None
+        L.mctsq_tree_backup.argtypes = [I64, P, P, P, P, P]
+        L.mctsq_tree_backup.restype = None
+        _TREE_LIB = L
+    return _TREE_LIB
 
 
 class LockstepMCTS:
@@ -69,8 +92,12 @@ class LockstepMCTS:
     """
 
     def __init__(self, n_trees: int, evaluate, iterations: int, maximum_depth: int, c_base: float, c_init: float,
-                 rngs=None, batch_env=None, seed: int = 0):
+                 rngs=None, batch_env=None, seed: int = 0, native: bool = True):
         self.K = int(n_trees)
+        # native: selection / backup loops in C (libmctsq_tree.so); False keeps them in numpy (same arithmetic, used
+        # by the tests to check the C path)
+        self.native = bool(native)
+        self._lib = _tree_lib() if self.native else None
         self.evaluate = evaluate
         self.iterations = int(iterations)
         self.maximum_depth = int(maximum_depth)
@@ -227,6 +254,29 @@ class LockstepMCTS:
             keep[np.asarray(mask, dtype=bool)] = -1
         self.root = self._retain(keep)
 
+    def _select_numpy(self, trees, maxd):
+        """Selection for all trees level by level (the arithmetic tree_ops.c repeats)."""
+        cur = self.root.copy()
+        while True:
+            terminal = self.done[cur] | (self.depth[cur] >= maxd)
+            go = ~terminal & (self.tried[cur] == self.legal[cur])
+            if not go.any():
+                break
+            t = trees[go]
+            node = cur[t]
+            ch = self.child[node]                                     # [n, 5] creation order
+            valid = ch >= 0
+            chs = np.where(valid, ch, 0)
+            v = np.where(valid, self.visits[chs], 0)
+            tv = v.sum(1)
+            c_puct = self._c_puct(tv)
+            vf = v.astype(np.float64)
+            mean = np.where(v > 0, self.total[chs] / np.where(v > 0, vf, 1.0), 0.0)
+            explore = c_puct[:, None] * self.prior_a[chs] * np.sqrt(tv.astype(np.float64))[:, None] / (1 + vf)
+            score = np.where(valid, mean + explore, -np.inf)
+            cur[t] = ch[np.arange(len(t)), np.argmax(score, axis=1)]
+        return cur
+
     # ---- the search ---------------------------------------------------------------------------
     def predict(self, state_cs, env_step=None, train: bool = True, push=None, reuse=None, push_rows=None):
         """One MCTS search per tree from state_cs[i]; returns the most-visited root action of every tree
@@ -254,26 +304,15 @@ class LockstepMCTS:
         trees = np.arange(K)
         maxd = self.maximum_depth
         for _ in range(self.iterations):
-            # -- selection (:266-308), all trees level by level
-            cur = self.root.copy()
-            while True:
-                terminal = self.done[cur] | (self.depth[cur] >= maxd)
-                go = ~terminal & (self.tried[cur] == self.legal[cur])
-                if not go.any():
-                    break
-                t = trees[go]
-                node = cur[t]
-                ch = self.child[node]                                     # [n, 5] creation order
-                valid = ch >= 0
-                chs = np.where(valid, ch, 0)
-                v = np.where(valid, self.visits[chs], 0)
-                tv = v.sum(1)
-                c_puct = self._c_puct(tv)
-                vf = v.astype(np.float64)
-                mean = np.where(v > 0, self.total[chs] / np.where(v > 0, vf, 1.0), 0.0)
-                explore = c_puct[:, None] * self.prior_a[chs] * np.sqrt(tv.astype(np.float64))[:, None] / (1 + vf)
-                score = np.where(valid, mean + explore, -np.inf)
-                cur[t] = ch[np.arange(len(t)), np.argmax(score, axis=1)]
+            # -- selection (:266-308)
+            if self.native:
+                cur = np.empty(K, dtype=np.int64)
+                self._lib.mctsq_tree_select(K, self.root.ctypes.data, maxd, float(self.c_base), float(self.c_init),
+                                            self.done.ctypes.data, self.depth.ctypes.data, self.legal.ctypes.data,
+                                            self.tried.ctypes.data, self.child.ctypes.data, self.visits.ctypes.data,
+                                            self.total.ctypes.data, self.prior_a.ctypes.data, cur.ctypes.data)
+            else:
+                cur = self._select_numpy(trees, maxd)
             # -- expansion (:312-356)
             terminal = self.done[cur] | (self.depth[cur] >= maxd)
             exp = trees[~terminal]
@@ -316,15 +355,20 @@ class LockstepMCTS:
                 cur[exp] = ids
                 self._evaluate_nodes(ids)                                  # ONE launch: the iteration's leaves
             # -- evaluation + backup (:358-381)
-            value = self.vmax[cur]
-            node = cur.copy()
-            live = node >= 0
-            while live.any():
-                nl = node[live]
-                self.visits[nl] += 1
-                self.total[nl] += value[live]
-                node[live] = self.parent[nl]
+            if self.native:
+                cur = np.ascontiguousarray(cur, dtype=np.int64)
+                self._lib.mctsq_tree_backup(K, cur.ctypes.data, self.vmax.ctypes.data, self.parent.ctypes.data,
+                                            self.visits.ctypes.data, self.total.ctypes.data)
+            else:
+                value = self.vmax[cur]
+                node = cur.copy()
                 live = node >= 0
+                while live.any():
+                    nl = node[live]
+                    self.visits[nl] += 1
+                    self.total[nl] += value[live]
+                    node[live] = self.parent[nl]
+                    live = node >= 0
         # -- most visited child, first maximum in creation order (:256, 553)
         if (self.nchild[self.root] == 0).any():
             raise ValueError("most_visited_child of a root without children (terminal root or iterations == 0)")

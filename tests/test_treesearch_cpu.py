@@ -179,3 +179,31 @@ def test_batched_mode_many_trees_invariants():
             if not term and drv.parent[n] >= 0:
                 assert drv.visits[n] == 1 + drv.visits[ch].sum()
     assert (runs[0][0] == runs[1][0]).all() and (runs[0][1] == runs[1][1]).all()
+
+
+@pytest.mark.parametrize("K,iters,horizon", [(1, 30, 3), (37, 20, 4), (300, 6, 6)])
+def test_native_select_and_backup_equal_numpy_path(K, iters, horizon):
+    """libmctsq_tree.so (csrc_host/tree_ops.c: PUCT selection and value backup over all trees, OpenMP over trees
+    from K = 256) against the numpy statements of the same loops: identical trees, bit for bit, over several
+    environment steps with sub-tree reuse."""
+    from mcts_q_amd.synthetic_env import FakeBatchEnv
+    net = _net(5)
+    runs = []
+    for native in (True, False):
+        benv = FakeBatchEnv(horizon=horizon)
+        drv = LockstepMCTS(K, _evaluator(net), iters, 42, 19652, 1.25, batch_env=benv, seed=11, native=native)
+        states = benv.reset(np.arange(K))
+        rec = []
+        for step in range(3):
+            a = drv.predict(states, train=True, reuse=np.ones(K, dtype=bool))
+            rec.append((a.copy(), drv.n, drv.visits[:drv.n].copy(), drv.total[:drv.n].copy(), drv.parent[:drv.n].copy()))
+            states, _, _, term, trunc, _ = benv.step_batch(states, a)
+            drv.advance(a, keep=~(np.asarray(term, dtype=bool) | np.asarray(trunc, dtype=bool)))
+            if (np.asarray(term, dtype=bool) | np.asarray(trunc, dtype=bool)).any():
+                break
+        runs.append(rec)
+    assert len(runs[0]) == len(runs[1])
+    for x, y in zip(*runs):
+        assert x[1] == y[1]
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)
