@@ -226,8 +226,9 @@ class LockstepMCTS:
         self.depth[:len(old_ids)] = rel[old_ids]                 # reset_depths (:239-243)
         self.parent[:len(old_ids)] = remap[self.parent[old_ids]]
         self.child[:len(old_ids)] = remap[self.child[old_ids]]
-        self.state_c[:len(old_ids)] = [self.state_c[i] for i in old_ids]
-        self.extra[:len(old_ids)] = [self.extra[i] for i in old_ids]
+        if self.batch_env is None:                                # per-environment mode keeps Python objects per node
+            self.state_c[:len(old_ids)] = [self.state_c[i] for i in old_ids]
+            self.extra[:len(old_ids)] = [self.extra[i] for i in old_ids]
         self.n = len(old_ids)
         new_roots = np.where(keep_roots >= 0, remap[keep_roots], -1)
         self.parent[new_roots[new_roots >= 0]] = -1               # detach from the previous root (:162)
