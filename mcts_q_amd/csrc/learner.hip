@@ -113,12 +113,167 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     }
 }
 
+// ---- the 192-128-128-A head backward on split-bf16 MFMA ----------------------------------------------------
+// Same arithmetic as the forward head (head_core.hpp): exact three-way split of both operands, six cross terms,
+// fp32 accumulate.  8 waves per 16-row tile; every wave fetches its (prepared, transposed, lane-major) weight
+// fragments of all three layers up front -- one round trip instead of a dependent global load per k-step --
+// and the deltas travel between layers as bf16 planes in LDS.
+constexpr int TB2 = 8 * 3, TB1 = 8 * 4 * 3, TB0 = 12 * 4 * 3;     // fragments per section
+static_assert(HEAD_PREP_BWD_BYTES == (int64_t)(TB2 + TB1 + TB0) * 64 * 16, "prepared backward head size");
+constexpr int DQP = 32 + 8, DPL = 128 + 8;                        // plane row strides (bf16 elements)
+
+#define HB_MM6(ACC, XH, XM, XL, W)                                                                 \
+    ACC = mfma_bf(XL, (W)[0], ACC); ACC = mfma_bf(XH, (W)[2], ACC); ACC = mfma_bf(XM, (W)[1], ACC); \
+    ACC = mfma_bf(XM, (W)[0], ACC); ACC = mfma_bf(XH, (W)[1], ACC); ACC = mfma_bf(XH, (W)[0], ACC);
+
+__global__ __launch_bounds__(512) void head_bwd_bf16_kernel(HeadBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short pq[3][TILE * DQP];
+    __shared__ __attribute__((aligned(16))) unsigned short pd[2][3][TILE * DPL];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jl = lane & 15, q = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * TILE;
+    const u32x4* hp = reinterpret_cast<const u32x4*>(a.wprep_bwd) + lane;
+    // fragments: W2 tile w; W1 tile w; W0 tiles w and (waves 0-3) w + 8
+    u32x4 f2[3], f1[12], f0[2][12];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) f2[f] = hp[(w * 3 + f) * 64];
+#pragma unroll
+    for (int f = 0; f < 12; ++f) f1[f] = hp[(TB2 + w * 12 + f) * 64];
+#pragma unroll
+    for (int f = 0; f < 12; ++f) f0[0][f] = hp[(TB2 + TB1 + w * 12 + f) * 64];
+    if (w < 4) {
+#pragma unroll
+        for (int f = 0; f < 12; ++f) f0[1][f] = hp[(TB2 + TB1 + (w + 8) * 12 + f) * 64];
+    }
+    // saved activations behind the derivative masks: rows 4q + r, column 16w + jl
+    float h1[4], h0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h1[r] = a.sv_act[1][(row0 + 4 * q + r) * 128 + 16 * w + jl];
+        h0[r] = a.sv_act[0][(row0 + 4 * q + r) * 128 + 16 * w + jl];
+    }
+    // dQ [16 x 16] -> planes, k padded to 32 with zeros
+    {
+        const int i = tid >> 5, c = tid & 31;
+        unsigned u0 = 0, u1 = 0, u2 = 0;
+        if (c < DQ_LD) split3(a.dq[(row0 + i) * DQ_LD + c], u0, u1, u2);
+        pq[0][i * DQP + c] = (unsigned short)(u0 >> 16);
+        pq[1][i * DQP + c] = (unsigned short)(u1 >> 16);
+        pq[2][i * DQP + c] = (unsigned short)(u2 >> 16);
+    }
+    __syncthreads();
+    auto mask = [&](float v, float h) { return a.act == MCTSQ_ACT_RELU ? (h > 0.0f ? v : 0.0f) : v * (1.0f - h * h); };
+    // ---- output layer: d1 = (dQ . W2) * act'(h1), column tile w --------------------------------------------
+    {
+        const int o = (lane & 15) * DQP + 8 * q;
+        const u32x4 xh = *reinterpret_cast<const u32x4*>(&pq[0][o]);
+        const u32x4 xm = *reinterpret_cast<const u32x4*>(&pq[1][o]);
+        const u32x4 xl = *reinterpret_cast<const u32x4*>(&pq[2][o]);
+        f32x4 acc = {0, 0, 0, 0};
+        HB_MM6(acc, xh, xm, xl, f2)
+        const int col = 16 * w + jl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = mask(acc[r], h1[r]);
+            a.d_act[1][(row0 + 4 * q + r) * 128 + col] = v;
+            unsigned u0, u1, u2;
+            split3(v, u0, u1, u2);
+            pd[1][0][(4 * q + r) * DPL + col] = (unsigned short)(u0 >> 16);
+            pd[1][1][(4 * q + r) * DPL + col] = (unsigned short)(u1 >> 16);
+            pd[1][2][(4 * q + r) * DPL + col] = (unsigned short)(u2 >> 16);
+        }
+    }
+    __syncthreads();
+    // ---- layer 1: d0 = (d1 . W1) * act'(h0), column tile w ---------------------------------------------------
+    {
+        const int o = (lane & 15) * DPL + 8 * q;
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(&pd[1][0][o + 32 * c]);
+            const u32x4 xm = *reinterpret_cast<const u32x4*>(&pd[1][1][o + 32 * c]);
+            const u32x4 xl = *reinterpret_cast<const u32x4*>(&pd[1][2][o + 32 * c]);
+            const u32x4 yh = *reinterpret_cast<const u32x4*>(&pd[1][0][o + 32 * c + 32]);
+            const u32x4 ym = *reinterpret_cast<const u32x4*>(&pd[1][1][o + 32 * c + 32]);
+            const u32x4 yl = *reinterpret_cast<const u32x4*>(&pd[1][2][o + 32 * c + 32]);
+            HB_MM6(acc0, xh, xm, xl, &f1[3 * c])
+            HB_MM6(acc1, yh, ym, yl, &f1[3 * c + 3])
+        }
+        const int col = 16 * w + jl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = mask(acc0[r] + acc1[r], h0[r]);
+            a.d_act[0][(row0 + 4 * q + r) * 128 + col] = v;
+            unsigned u0, u1, u2;
+            split3(v, u0, u1, u2);
+            pd[0][0][(4 * q + r) * DPL + col] = (unsigned short)(u0 >> 16);
+            pd[0][1][(4 * q + r) * DPL + col] = (unsigned short)(u1 >> 16);
+            pd[0][2][(4 * q + r) * DPL + col] = (unsigned short)(u2 >> 16);
+        }
+    }
+    __syncthreads();
+    // ---- layer 0: dfeat = d0 . W0, column tiles w and (waves 0-3) w + 8 --------------------------------------
+    {
+        const int o = (lane & 15) * DPL + 8 * q;
+        f32x4 acc[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(&pd[0][0][o + 32 * c]);
+            const u32x4 xm = *reinterpret_cast<const u32x4*>(&pd[0][1][o + 32 * c]);
+            const u32x4 xl = *reinterpret_cast<const u32x4*>(&pd[0][2][o + 32 * c]);
+            HB_MM6(acc[0][c & 1], xh, xm, xl, &f0[0][3 * c])
+            if (w < 4) { HB_MM6(acc[1][c & 1], xh, xm, xl, &f0[1][3 * c]) }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.dfeat[(row0 + 4 * q + r) * FEAT + 16 * w + jl] = acc[0][0][r] + acc[0][1][r];
+            if (w < 4) a.dfeat[(row0 + 4 * q + r) * FEAT + 16 * (w + 8) + jl] = acc[1][0][r] + acc[1][1][r];
+        }
+    }
+}
+#undef HB_MM6
+
+// one thread per (fragment group, lane): 8 k-values (output units) of one input column -> 3 x 8 bf16
+__global__ __launch_bounds__(256) void head_prepare_bwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                               const float* __restrict__ w2, int A, u32x4* __restrict__ out) {
+    const int tid = blockIdx.x * 256 + threadIdx.x, lane = tid & 63, fg = tid >> 6;   // 8 + 32 + 48 groups
+    if (fg >= 88) return;
+    const int jl = lane & 15, q = lane >> 4;
+    const float* W;
+    int N, K, tile, c, base;
+    if (fg < 8) { W = w2; N = 128; K = A; tile = fg; c = 0; base = fg * 3; }
+    else if (fg < 40) { const int f = fg - 8; W = w1; N = 128; K = 128; tile = f >> 2; c = f & 3; base = TB2 + f * 3; }
+    else { const int f = fg - 40; W = w0; N = FEAT; K = 128; tile = f >> 2; c = f & 3; base = TB2 + TB1 + f * 3; }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 32 * c + 8 * q + e;
+        v[e] = k < K ? W[(int64_t)k * N + 16 * tile + jl] : 0.0f;
+    }
+    u32x4 hi, mid, lo;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, mid, lo);
+    out[(base + 0) * 64 + lane] = hi; out[(base + 1) * 64 + lane] = mid; out[(base + 2) * 64 + lane] = lo;
+}
+int launch_head_prepare_bwd(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st) {
+    MCTSQ_CHECK(w0 && w1 && w2 && prep && A >= 1 && A <= 16, "head backward prepare: bad arguments");
+    hipLaunchKernelGGL(head_prepare_bwd_kernel, dim3((88 * 64 + 255) / 256), dim3(256), 0, st, w0, w1, w2, A,
+                       reinterpret_cast<u32x4*>(prep));
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
     for (int l = 0; l < a.n_fc; ++l) {
         MCTSQ_CHECK(a.in[l] % 16 == 0 && a.in[l] <= 256, "head backward layer %d: width %d unsupported", l, a.in[l]);
         MCTSQ_CHECK(a.out[l] <= 256, "head backward layer %d: width %d unsupported", l, a.out[l]);
     }
     MCTSQ_CHECK(a.out[a.n_fc - 1] <= DQ_LD, "action_dim > %d", DQ_LD);
+    if (a.wprep_bwd && a.n_fc == 3 && a.in[0] == FEAT && a.out[0] == 128 && a.in[1] == 128 && a.out[1] == 128 &&
+        a.in[2] == 128) {
+        hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3((unsigned)(a.Bp / TILE)), dim3(512), 0, st, a);
+        MCTSQ_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(a.Bp / TILE)), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;

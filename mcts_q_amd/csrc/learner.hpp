@@ -31,8 +31,13 @@ struct HeadBwdArgs {
     const float* sv_act[4];     // post-activation hidden layers [Bp][H]
     float* d_act[4];            // out: d(pre-activation) of hidden layer l, [Bp][H]
     float* dfeat;               // out: [Bp][192]
+    const void* wprep_bwd;      // 192-128-128-A head only: transposed split-bf16 fragments (head_prepare_bwd_kernel), or NULL
 };
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);
+// The head's weights as B operands of d(in) = d(out) . W (k = output unit, n = input unit), split into bf16 planes,
+// lane-major: u32x4 [W2: tile 8][plane 3], [W1: tile 8][K chunk 4][plane 3], [W0: tile 12][K chunk 4][plane 3], 64 lanes each
+constexpr int64_t HEAD_PREP_BWD_BYTES = (int64_t)(8 * 3 + 8 * 4 * 3 + 12 * 4 * 3) * 64 * 16;
+int launch_head_prepare_bwd(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st);
 
 // ---- GRU-attention backward: LayerNorm, attention pooling, BPTT (deltas only) ----
 struct GruBwdArgs {

@@ -42,6 +42,7 @@ struct TrainPlan {
     int64_t Bp;
     int64_t feats_t, q_t, qnext, feats_p, q_p, dq, dfeat;
     int64_t act[4], dact[4];
+    int64_t head_prep_bwd;                               // transposed split-bf16 head fragments (-1: generic head)
     SlotPlan slot[3];
     int64_t partials, partial_floats;
     int64_t total;                                       // floats
@@ -69,6 +70,9 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
         P->act[i] = c.take(Bp * L.fc_out[i]);
         P->dact[i] = c.take(Bp * L.fc_out[i]);
     }
+    const bool head_bf16 = L.n_fc == 3 && L.fc_in[0] == FEAT && L.fc_out[0] == 128 && L.fc_in[1] == 128 &&
+                           L.fc_out[1] == 128 && L.fc_in[2] == 128 && L.A <= 16;
+    P->head_prep_bwd = head_bf16 ? c.take(HEAD_PREP_BWD_BYTES / (int64_t)sizeof(float)) : -1;
     int64_t pf = 0;
     for (int s = 0; s < 3; ++s) {
         const EncOff& e = L.enc[s];
@@ -242,6 +246,11 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         // the flat gradient's alignment pads must read zero; nothing touches it before the ordered reduction (step 7,
         // behind the join), so the fill rides on the helper stream instead of the critical path
         MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
+        // ... and so does the split of the head weights the backward pass multiplies by
+        if (P.head_prep_bwd >= 0 &&
+            launch_head_prepare_bwd(d_params + L.fc_w[0], d_params + L.fc_w[1], d_params + L.fc_w[2], L.A,
+                                    ws + P.head_prep_bwd, side->st))
+            return -1;
         const float* x[3] = {d_nprice, d_nprocess, d_ngas};
         HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
         if (forward_impl(L, d_target_params, nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, side->st, nullptr))
@@ -299,6 +308,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         h.n_fc = L.n_fc; h.act = L.act; h.Bp = Bp; h.dq = ws + P.dq; h.dfeat = ws + P.dfeat;
         for (int i = 0; i < L.n_fc; ++i) { h.w[i] = d_params + L.fc_w[i]; h.in[i] = L.fc_in[i]; h.out[i] = L.fc_out[i]; }
         for (int i = 0; i + 1 < L.n_fc; ++i) { h.sv_act[i] = ws + P.act[i]; h.d_act[i] = ws + P.dact[i]; }
+        h.wprep_bwd = P.head_prep_bwd >= 0 ? ws + P.head_prep_bwd : nullptr;
         if (launch_head_bwd(h, st)) return -1;
     }
     // 5. encoder backward (deltas)
