@@ -9,6 +9,7 @@ struct GruSlot {
     const float* x;                      // [B][S][Fd]
     const float *wih, *whh, *bih, *bhh, *aw, *ab, *lnw, *lnb;
     const void* wprep;                   // W_hh split into bf16 planes in fragment order (gru_prepare_kernel)
+    const void* wprep_t;                 // training: W_hh as B operand of delta . W_hh, split, lane-major (gru_prepare_bwd_kernel)
     int S, Fd, F, tf, out_col;
     // training-time activation record (NULL for inference), Bp = padded batch
     float* sv_h;                         // [S+1][Bp][64]: block 0 = h_{-1} = 0, block t+1 = h_t

@@ -284,10 +284,10 @@ int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st) {
 // the same ownership as the forward: wave wq holds hidden units 16wq..16wq+15, lane register r is
 // sample 4q+r.  Per step the hidden-state gradient needs [16 x 192].[192 x 64] (delta . W_hh):
 // delta goes through a double-buffered LDS tile, W_hh columns stay in 48 VGPRs per lane.
-constexpr int GLD = 196;     // LDS row stride of the delta tile (192 + 4)
+constexpr int GPL = 192 + 8;  // row stride (bf16 elements) of a delta plane: 400 B, b128 reads conflict-free
 
 struct GruBwdLds {
-    float g[2][TILE * GLD];
+    unsigned short gp[2][3][TILE * GPL];   // delta tile [drp | dzp | ghn] as bf16 planes (hi, mid, lo), double buffered
     float4 pe[MAX_SEQ][TILE];       // per-wave partials of e_t = dpool . h_t
     float red[3][4][TILE];
 };
@@ -302,10 +302,17 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     const int S = s.S;
     const int64_t Bp = args.Bp;
 
-    // W_hh columns: B operand of the delta . W_hh product, k = 48q + c (gate row), col = unit j
-    float wf[48];
+    // W_hh as B operand of the delta . W_hh product (k = gate row, col = unit j): prepared split-bf16 fragments,
+    // 6 K chunks x 3 planes resident in 72 VGPRs.  The product runs on the bf16 matrix instruction over the exact
+    // three-way split of both operands (six cross terms, fp32 accumulate), like the forward recurrence.
+    u32x4 wt[6][3];
+    {
+        const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep_t) + (int64_t)wq * (6 * 3 * 64) + lane;
 #pragma unroll
-    for (int c = 0; c < 48; ++c) wf[c] = s.whh[(int64_t)(48 * q + c) * E + j];
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wt[c][pl] = wp[(c * 3 + pl) * 64];
+    }
     const float lnw = s.lnw[j], awj = s.aw[j];
 
     // ---- LayerNorm backward -> dpool -------------------------------------------------------
@@ -340,15 +347,15 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         const float v = row16_sum(dpool[r] * pooled[r]);
         if (jl == 0) L.red[2][wq][4 * q + r] = v;
     }
-    for (int t0 = 0; t0 < S; t0 += 8) {                       // 32 loads in flight per lane, then the sums
-        float hv[8][4];
+    for (int t0 = 0; t0 < S; t0 += 16) {                      // 64 loads in flight per lane, then the sums
+        float hv[16][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 hv[u][r] = t0 + u < S ? s.sv_h[((int64_t)(t0 + u + 1) * Bp + row0 + 4 * q + r) * E + j] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             if (t0 + u >= S) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     // The saved activations of step t-1 are fetched while step t's MFMA chain runs, so the
     // recurrence never waits on HBM/L2 latency.
     struct StepIn { float rg, zg, ng, hn, hprev, sc; };
-    StepIn cur[4], nxt[4];
+    StepIn sb0[4], sb1[4], sb2[4];         // three steps of saved activations in flight (HBM latency > one step)
     auto fetch = [&](StepIn (&d)[4], int t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -380,7 +387,9 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             d[r].sc = s.sv_score[row];
         }
     };
-    fetch(cur, S - 1);
+    fetch(sb0, S - 1);
+    if (S >= 2) fetch(sb1, S - 2);
+    if (S >= 3) fetch(sb2, S - 3);
     // gradient of the score Linear(64,1): d_aw[j] = sum_{t,row} dsc * h_t[row][j], d_ab = sum dsc.  h_t is
     // the h_{t-1} operand of the step handled just before (the loop runs backwards); the tile's sums
     // go out as one partial, reduced over tiles in order by wgrad_reduce_kernel.
@@ -388,9 +397,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) hnext[r] = s.sv_h[((int64_t)S * Bp + row0 + 4 * q + r) * E + j];
     float dhc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int t = S - 1; t >= 0; --t) {
+    auto bptt_step = [&](int t, StepIn (&cur)[4]) {
         const int buf = t & 1;
-        if (t > 0) fetch(nxt, t - 1);
         float zs[4], dhs[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -410,27 +418,46 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             const float ghn = dnp * rg;
             float* grow = s.bw_g + row * 256;
             grow[j] = drp; grow[E + j] = dzp; grow[2 * E + j] = dnp; grow[3 * E + j] = ghn;
-            float* lrow = &L.g[buf][i * GLD];
-            lrow[j] = drp; lrow[E + j] = dzp; lrow[2 * E + j] = ghn;
+            {
+                const float dv[3] = {drp, dzp, ghn};
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                    unsigned u0, u1, u2;
+                    split3(dv[g3], u0, u1, u2);
+                    L.gp[buf][0][i * GPL + g3 * E + j] = (unsigned short)(u0 >> 16);
+                    L.gp[buf][1][i * GPL + g3 * E + j] = (unsigned short)(u1 >> 16);
+                    L.gp[buf][2][i * GPL + g3 * E + j] = (unsigned short)(u2 >> 16);
+                }
+            }
             zs[r] = zg; dhs[r] = dh;
         }
-        if (t == 0) break;                                     // dh_{-1} is not needed
+        if (t >= 3) fetch(cur, t - 3);                         // this buffer's next occupant starts its trip
+        if (t == 0) return;                                    // dh_{-1} is not needed
         __syncthreads();
-        const float4* ga = reinterpret_cast<const float4*>(&L.g[buf][(lane & 15) * GLD + 48 * q]);
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 a0 = ga[c], a1 = ga[4 + c], a2 = ga[8 + c];
-            acc0 = mfma16(a0.x, wf[4 * c + 0], acc0); acc1 = mfma16(a1.x, wf[16 + 4 * c + 0], acc1); acc2 = mfma16(a2.x, wf[32 + 4 * c + 0], acc2);
-            acc0 = mfma16(a0.y, wf[4 * c + 1], acc0); acc1 = mfma16(a1.y, wf[16 + 4 * c + 1], acc1); acc2 = mfma16(a2.y, wf[32 + 4 * c + 1], acc2);
-            acc0 = mfma16(a0.z, wf[4 * c + 2], acc0); acc1 = mfma16(a1.z, wf[16 + 4 * c + 2], acc1); acc2 = mfma16(a2.z, wf[32 + 4 * c + 2], acc2);
-            acc0 = mfma16(a0.w, wf[4 * c + 3], acc0); acc1 = mfma16(a1.w, wf[16 + 4 * c + 3], acc1); acc2 = mfma16(a2.w, wf[32 + 4 * c + 3], acc2);
+        {
+            const int o = (lane & 15) * GPL + 8 * q;
+#define GB_MM6(ACC, C)                                                                                         \
+            {                                                                                                  \
+                const u32x4 xh = *reinterpret_cast<const u32x4*>(&L.gp[buf][0][o + 32 * (C)]);                 \
+                const u32x4 xm = *reinterpret_cast<const u32x4*>(&L.gp[buf][1][o + 32 * (C)]);                 \
+                const u32x4 xl = *reinterpret_cast<const u32x4*>(&L.gp[buf][2][o + 32 * (C)]);                 \
+                ACC = mfma_bf(xl, wt[C][0], ACC); ACC = mfma_bf(xh, wt[C][2], ACC); ACC = mfma_bf(xm, wt[C][1], ACC); \
+                ACC = mfma_bf(xm, wt[C][0], ACC); ACC = mfma_bf(xh, wt[C][1], ACC); ACC = mfma_bf(xh, wt[C][0], ACC); \
+            }
+            GB_MM6(acc0, 0) GB_MM6(acc1, 2) GB_MM6(acc2, 4)
+            GB_MM6(acc0, 1) GB_MM6(acc1, 3) GB_MM6(acc2, 5)
+#undef GB_MM6
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dhc[r] = dhs[r] * zs[r] + ((acc0[r] + acc1[r]) + acc2[r]);
-            cur[r] = nxt[r];
         }
+    };
+    for (int t = S - 1; t >= 0; t -= 3) {                      // unrolled by three: the buffers keep their roles
+        bptt_step(t, sb0);
+        if (t >= 1) bptt_step(t - 1, sb1);
+        if (t >= 2) bptt_step(t - 2, sb2);
     }
     daw += __shfl_xor(daw, 16, 64); daw += __shfl_xor(daw, 32, 64);
     dab += __shfl_xor(dab, 16, 64); dab += __shfl_xor(dab, 32, 64);
@@ -439,10 +466,35 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     if (wq == 0 && lane == 0) pa[64] = dab;
 }
 
+struct GruPrepBwdArgs { const float* whh[3]; u32x4* out[3]; };
+__global__ __launch_bounds__(256) void gru_prepare_bwd_kernel(GruPrepBwdArgs a) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;           // grid = n * 6 blocks of 256
+    const int lane = tid & 63, rest = tid >> 6, c = rest % 6, wq = (rest / 6) & 3, slot = rest / 24;
+    const int jl = lane & 15, q = lane >> 4;
+    const float* w = a.whh[slot] + (int64_t)(32 * c + 8 * q) * E + 16 * wq + jl;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[e * E];
+    u32x4 hi, mid, lo;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, mid, lo);
+    u32x4* o = a.out[slot] + ((wq * 6 + c) * 3) * 64 + lane;
+    o[0] = hi; o[64] = mid; o[128] = lo;
+}
+int launch_gru_prepare_bwd(const float* const whh[3], int n, void* const out[3], hipStream_t st) {
+    if (n == 0) return 0;
+    GruPrepBwdArgs a;
+    for (int i = 0; i < 3; ++i) { a.whh[i] = whh[i < n ? i : 0]; a.out[i] = reinterpret_cast<u32x4*>(out[i < n ? i : 0]); }
+    hipLaunchKernelGGL(gru_prepare_bwd_kernel, dim3((unsigned)(n * 6)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
     if (a.nslots == 0) return 0;
     MCTSQ_CHECK(a.Bp % TILE == 0, "padded batch must be a multiple of %d", TILE);
     for (int i = 0; i < a.nslots; ++i) MCTSQ_CHECK(a.slot[i].S <= MAX_SEQ, "window too long");
+    for (int i = 0; i < a.nslots; ++i)
+        MCTSQ_CHECK(a.slot[i].wprep_t && ((uintptr_t)a.slot[i].wprep_t & 15) == 0, "GRU backward needs the transposed prepared weights");
     hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)(a.Bp / TILE * a.nslots)), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;

@@ -46,6 +46,9 @@ struct GruBwdArgs {
     int64_t Bp;
     const float* dfeat;         // [Bp][192]
 };
+// W_hh [192][64] as the B operand of the BPTT product delta [16 x 192] . W_hh: u32x4 [wave 4][K chunk 6][plane 3][lane 64],
+// lane (jl, q) of wave w holds W_hh[32c + 8q .. +7][16w + jl]; GRU_PREP_BYTES per slot
+int launch_gru_prepare_bwd(const float* const whh[3], int n, void* const out[3], hipStream_t st);
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
 
 // ---- GRU weight gradients, all of one slot's big contractions in one pass over the saved tensors ----

@@ -27,6 +27,7 @@ struct SlotPlan {                      // float offsets; which fields are used d
     int64_t score, stat, pool, x, dsc, p;
     int64_t h, r, z, n, hn, g;          // gru
     int64_t wp_ih, wp_rz, wp_n, wp_aw;  // gru: partials of the fused weight-gradient kernel / of gru_bwd_kernel
+    int64_t wt;                         // gru: W_hh as split-bf16 B fragments of the BPTT product (gru_prepare_bwd_kernel)
     int gw_rows, gw_nsplit;
     int64_t c_h1, c_h2, c_d2, c_d1;     // conv
     int64_t m_x, m_m0, m_d1, m_d0;      // mlp
@@ -89,6 +90,7 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
             g.wp_rz = c.take((int64_t)g.gw_nsplit * (128 * E + 128));
             g.wp_n = c.take((int64_t)g.gw_nsplit * (E * E + E));
             g.wp_aw = c.take(Bp / TILE * 65);
+            g.wt = c.take(GRU_PREP_BYTES / (int64_t)sizeof(float));
             pf += 2 * job_partial_floats(E, 0, Bp);
         } else if (e.kind == MCTSQ_ENC_CONV) {
             g.c_h1 = c.take((S + 2) * Bp * E); g.c_h2 = c.take(K * E);
@@ -251,6 +253,14 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
             launch_head_prepare_bwd(d_params + L.fc_w[0], d_params + L.fc_w[1], d_params + L.fc_w[2], L.A,
                                     ws + P.head_prep_bwd, side->st))
             return -1;
+        {                                                    // ... and of W_hh for the BPTT product
+            const float* whh[3] = {nullptr, nullptr, nullptr};
+            void* wt[3] = {nullptr, nullptr, nullptr};
+            int n = 0;
+            for (int s = 0; s < 3; ++s)
+                if (L.enc[s].kind == MCTSQ_ENC_GRU) { whh[n] = d_params + L.enc[s].gru.whh; wt[n] = ws + P.slot[s].wt; ++n; }
+            if (launch_gru_prepare_bwd(whh, n, wt, side->st)) return -1;
+        }
         const float* x[3] = {d_nprice, d_nprocess, d_ngas};
         HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
         if (forward_impl(L, d_target_params, nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, side->st, nullptr))
@@ -326,6 +336,8 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         memset(&gb, 0, sizeof(gb));
         gb.nslots = ga.nslots; gb.Bp = Bp; gb.dfeat = ws + P.dfeat;
         for (int i = 0; i < ga.nslots; ++i) gb.slot[i] = ga.slot[i];
+        for (int s = 0, i = 0; s < 3; ++s)
+            if (L.enc[s].kind == MCTSQ_ENC_GRU) gb.slot[i++].wprep_t = ws + P.slot[s].wt;
         if (launch_gru_bwd(gb, st)) return -1;
         MlpArgs ma;
         if (fill_mlp_args(ma, L, d_params, xs, B, Bp, ws + P.feats_p, sv)) {
