@@ -347,15 +347,15 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         const float v = row16_sum(dpool[r] * pooled[r]);
         if (jl == 0) L.red[2][wq][4 * q + r] = v;
     }
-    for (int t0 = 0; t0 < S; t0 += 16) {                      // 64 loads in flight per lane, then the sums
-        float hv[16][4];
+    for (int t0 = 0; t0 < S; t0 += 8) {                       // 32 loads in flight per lane, then the sums
+        float hv[8][4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 hv[u][r] = t0 + u < S ? s.sv_h[((int64_t)(t0 + u + 1) * Bp + row0 + 4 * q + r) * E + j] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 8; ++u) {
             if (t0 + u >= S) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
