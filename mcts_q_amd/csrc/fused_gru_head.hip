@@ -48,9 +48,6 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
     const int sa = grp == 0 ? big : (big == 0 ? 1 : 0);
     const int sb = big == 2 ? 1 : 2;
 
-#ifdef MCTSQ_EXP_PRIO
-    if (grp == 1) __builtin_amdgcn_s_setprio(MCTSQ_EXP_PRIO); else __builtin_amdgcn_s_setprio(0);
-#endif
     STAMP(0);
     GruWave<SAVE> g;
     g.bind(lane, wq);

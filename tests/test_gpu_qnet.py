@@ -160,3 +160,33 @@ def test_gru_sharp_attention_uses_running_max(B):
     q = net(price.cuda(), process.cuda(), gas.cuda())["q"].cpu().numpy()
     assert np.isfinite(q).all()
     assert np.abs(q - ref64).max() <= 1e-5 * np.abs(ref64).max()
+
+
+@pytest.mark.parametrize("name", ["gru_gru_gru_per_relu", "conv_conv_mlp_per_relu", "transformer_transformer_gru_per_relu",
+                                  "conv_gru_mlp_per_relu"])
+def test_self_preparing_entry_point_equals_prepared_one(name):
+    """mctsq_q_forward splits the weights into its workspace on every call; mctsq_q_forward_prepared takes the
+    caller's prepared buffer (what DeviceQNet uses).  Same kernels, same fragments: bit-identical outputs."""
+    import ctypes as C
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd._lib import lib, ptr
+    from mcts_q_amd.qnet import DeviceQNet, _stream_ptr
+    path = os.path.join(GOLDEN, f"qnet_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("no golden file for this mix")
+    z, cfg, sd = _load(path)
+    B = 77
+    g = torch.Generator().manual_seed(3)
+    x = [torch.rand(B, 25, 1, generator=g).cuda(), torch.rand(B, 10, 6, generator=g).cuda(), torch.rand(B, 3, 2, generator=g).cuda()]
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    ref = net(*x)
+    A = net.spec.action_dim
+    q = torch.empty(B, A, device="cuda"); vmax = torch.empty(B, device="cuda")
+    arg = torch.empty(B, dtype=torch.int32, device="cuda"); prior = torch.empty(B, A, device="cuda")
+    nbytes = lib.check(lib.mctsq_q_forward_workspace_bytes(C.byref(net.desc), B))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    lib.check(lib.mctsq_q_forward(C.byref(net.desc), ptr(net.flat), ptr(x[0]), ptr(x[1]), ptr(x[2]), B, ptr(q), ptr(vmax),
+                                  ptr(arg), ptr(prior), ptr(ws), ws.numel(), _stream_ptr(net.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(q, ref["q"]) and torch.equal(vmax, ref["vmax"])
+    assert torch.equal(arg, ref["argmax"]) and torch.equal(prior, ref["prior"])
