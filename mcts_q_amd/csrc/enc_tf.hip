@@ -14,27 +14,40 @@ constexpr int TOK_PER_WAVE = 64;
 constexpr int TOK_PER_WG = 256;
 
 // -------------------------------------------------------------------------------- embedding
+// One workgroup = 16 tokens x 64 columns; a thread keeps its column of the embedding weights in registers and
+// walks 4 consecutive tokens (one division per thread, (sample, step) advanced incrementally).
 __global__ __launch_bounds__(256) void tf_embed_kernel(TfArgs a) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t tok = gid >> 6;
-    const int c = (int)(gid & 63);
-    if (tok >= a.Tp) return;
-    float v = 0.0f;
-    if (tok < a.Bvalid * a.S) {
-        const int64_t b = tok / a.S;
-        const int t = (int)(tok - b * a.S);
-        v = a.eb[c];
-        for (int f = 0; f < a.F; ++f) {
-            const float x = f < a.Fd ? a.x[tok * a.Fd + f] : time_feature(a.tf, t, f - a.Fd);
-            v = fmaf(x, a.ew[c * a.F + f], v);
-            if (a.sv_xe && c == 0) a.sv_xe[tok * 8 + f] = x;
+    const int c = threadIdx.x & 63;
+    const int64_t tok0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4;    // < Tp (grid = Tp / 16)
+    float w[MAX_F];
+#pragma unroll
+    for (int f = 0; f < MAX_F; ++f) w[f] = f < a.F ? a.ew[c * a.F + f] : 0.0f;
+    const float bias = a.eb[c];
+    int64_t b = tok0 / a.S;
+    int t = (int)(tok0 - b * a.S);
+    const int64_t nvalid = a.Bvalid * a.S;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t tok = tok0 + u;
+        float v = 0.0f;
+        if (tok < nvalid) {
+            v = bias;
+#pragma unroll
+            for (int f = 0; f < MAX_F; ++f) {
+                if (f < a.F) {
+                    const float x = f < a.Fd ? a.x[tok * a.Fd + f] : time_feature(a.tf, t, f - a.Fd);
+                    v = fmaf(x, w[f], v);
+                    if (a.sv_xe && c == 0) a.sv_xe[tok * 8 + f] = x;
+                }
+            }
+            if (a.sv_xe && c >= a.F && c < 8) a.sv_xe[tok * 8 + c] = 0.0f;
+            v += a.pos[t * E + c];
+        } else if (a.sv_xe && c < 8) {
+            a.sv_xe[tok * 8 + c] = 0.0f;
         }
-        if (a.sv_xe && c >= a.F && c < 8) a.sv_xe[tok * 8 + c] = 0.0f;
-        v += a.pos[t * E + c];
-    } else if (a.sv_xe && c < 8) {
-        a.sv_xe[tok * 8 + c] = 0.0f;
+        a.buf[0].hin[tok * E + c] = v;
+        if (++t == a.S) { t = 0; ++b; }
     }
-    a.buf[0].hin[tok * E + c] = v;
 }
 
 // LayerNorm over the 64 columns of rows held in the MFMA D layout: x[c][r] is column 16c + jl of
@@ -438,7 +451,7 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
     MCTSQ_CHECK(a.Tp % TOK_PER_WG == 0 && a.Tp >= a.T && a.T == a.B * a.S, "transformer encoder: bad token padding");
     MCTSQ_CHECK(a.NS >= 1 && a.NS * a.S <= AROWS, "transformer encoder: samples per workgroup");
     MCTSQ_CHECK(a.ffn_prep[0] && a.ffn_prep[1], "transformer encoder needs prepared FFN weights");
-    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp * E / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp / 16)), dim3(256), 0, st, a);
     const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / TOK_PER_WG);
     for (int l = 0; l < 2; ++l) {
         hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(256), 0, st, a, l);
