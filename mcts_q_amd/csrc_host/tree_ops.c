@@ -6,6 +6,7 @@
  * against each other.  Built by mcts_q_amd/csrc/Makefile into mcts_q_amd/lib/libmctsq_tree.so (gcc, no GPU code). */
 #include <math.h>
 #include <stdint.h>
+#include "../../include/mctsq_tree.h"
 
 #define N_ACT 5
 

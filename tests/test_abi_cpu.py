@@ -38,3 +38,13 @@ def test_host_side_queries_need_no_gpu():
     assert lib.mctsq_per_tree_words(1_000_000) > 1_000_000
     assert lib.mctsq_q_forward_workspace_bytes(ctypes.byref(d), -1) < 0
     assert b"negative" in lib.mctsq_last_error()
+
+
+def test_host_tree_helper_exports_its_header():
+    """libmctsq_tree.so (host-only C helper of the lock-step search) exports what include/mctsq_tree.h declares."""
+    text = open(os.path.join(ROOT, "include", "mctsq_tree.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mctsq_tree_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["mctsq_tree_backup", "mctsq_tree_select"]
+    dll = ctypes.CDLL(os.path.join(ROOT, "mcts_q_amd", "lib", "libmctsq_tree.so"))
+    assert all(hasattr(dll, n) for n in names)
