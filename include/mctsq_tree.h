@@ -24,6 +24,15 @@ void mctsq_tree_select(int64_t K, const int64_t* root, int64_t maxd, double c_ba
 void mctsq_tree_backup(int64_t K, const int64_t* leaf, const double* vmax, const int64_t* parent, int64_t* visits,
                        double* total);
 
+/* Sub-tree reuse (replaces the re-rooting of src/mctsq_config_mcts_per.py:153-167 and reset_depths, :236-247): keeps
+ * the nodes under keep_roots[k] (>= 0; -1 = drop tree k), compacts all per-node arrays in place in ascending id order
+ * and resets depths relative to the new roots.  rel, newid: scratch, n int64 each.  Returns the new node count. */
+int64_t mctsq_tree_retain(int64_t K, int64_t n, const int64_t* keep_roots, int64_t* new_roots, int64_t* parent,
+                          int64_t* action, int64_t* visits, double* total, int64_t* depth, uint8_t* done,
+                          int64_t* legal, int64_t* tried, int64_t* nchild, int64_t* child, double* vmax,
+                          double* prior_a, float* rows, int64_t row_w, double* svec, int64_t D, int64_t* rel,
+                          int64_t* newid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,49 @@ void mctsq_tree_backup(int64_t K, const int64_t* leaf, const double* vmax, const
         }
     }
 }
+
+/* Sub-tree reuse (mctsq_config_mcts_per.py:153-167, 236-247): keep only the nodes under keep_roots[k] (>= 0), compact
+ * every per-node array in place in ascending id order (children are always created after their parents, so the
+ * order -- and with it every id the numpy path would assign -- is preserved), re-root the kept trees at depth 0.
+ * rel / newid: scratch of n int64 each.  Returns the new node count; new_roots[k] = new id of keep_roots[k] or -1. */
+int64_t mctsq_tree_retain(int64_t K, int64_t n, const int64_t* keep_roots, int64_t* new_roots, int64_t* parent,
+                          int64_t* action, int64_t* visits, double* total, int64_t* depth, uint8_t* done,
+                          int64_t* legal, int64_t* tried, int64_t* nchild, int64_t* child, double* vmax,
+                          double* prior_a, float* rows, int64_t row_w, double* svec, int64_t D, int64_t* rel,
+                          int64_t* newid) {
+    for (int64_t i = 0; i < n; ++i) rel[i] = -1;
+    /* breadth-first marking; newid doubles as the queue until the ids are assigned */
+    int64_t qh = 0, qt = 0;
+    for (int64_t k = 0; k < K; ++k)
+        if (keep_roots[k] >= 0) { rel[keep_roots[k]] = 0; newid[qt++] = keep_roots[k]; }
+    while (qh < qt) {
+        const int64_t node = newid[qh++];
+        const int64_t* ch = child + node * N_ACT;
+        for (int a = 0; a < N_ACT; ++a)
+            if (ch[a] >= 0) { rel[ch[a]] = rel[node] + 1; newid[qt++] = ch[a]; }
+    }
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) newid[i] = rel[i] >= 0 ? m++ : -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t j = newid[i];
+        if (j < 0) continue;
+        action[j] = action[i]; visits[j] = visits[i]; total[j] = total[i]; done[j] = done[i];
+        legal[j] = legal[i]; tried[j] = tried[i]; nchild[j] = nchild[i]; vmax[j] = vmax[i]; prior_a[j] = prior_a[i];
+        depth[j] = rel[i];
+        const int64_t p = parent[i];
+        parent[j] = p >= 0 ? newid[p] : -1;
+        for (int a = 0; a < N_ACT; ++a) {
+            const int64_t c = child[i * N_ACT + a];
+            child[j * N_ACT + a] = c >= 0 ? newid[c] : -1;
+        }
+        if (j != i) {
+            for (int64_t c = 0; c < row_w; ++c) rows[j * row_w + c] = rows[i * row_w + c];
+            for (int64_t c = 0; c < D; ++c) svec[j * D + c] = svec[i * D + c];
+        }
+    }
+    for (int64_t k = 0; k < K; ++k) {
+        new_roots[k] = keep_roots[k] >= 0 ? newid[keep_roots[k]] : -1;
+        if (new_roots[k] >= 0) parent[new_roots[k]] = -1;      /* detach from the previous root (:162) */
+    }
+    return m;
+}

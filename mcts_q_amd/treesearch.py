@@ -65,6 +65,8 @@ def _tree_lib():
         L.mctsq_tree_select.restype = None
         L.mctsq_tree_backup.argtypes = [I64, P, P, P, P, P]
         L.mctsq_tree_backup.restype = None
+        L.mctsq_tree_retain.argtypes = [I64, I64] + [P] * 15 + [I64, P, I64, P, P]
+        L.mctsq_tree_retain.restype = I64
         _TREE_LIB = L
     return _TREE_LIB
 
@@ -206,6 +208,17 @@ class LockstepMCTS:
         if self.n == 0 or not (keep_roots >= 0).any():
             self.n = 0
             return np.full(K, -1, dtype=np.int64)
+        if self.native and self.batch_env is not None:            # no per-node Python objects to carry along
+            keep_roots = np.ascontiguousarray(keep_roots, dtype=np.int64)
+            new_roots = np.empty(K, dtype=np.int64)
+            rel, newid = np.empty(self.n, dtype=np.int64), np.empty(self.n, dtype=np.int64)
+            self.n = int(self._lib.mctsq_tree_retain(
+                K, self.n, keep_roots.ctypes.data, new_roots.ctypes.data, self.parent.ctypes.data,
+                self.action.ctypes.data, self.visits.ctypes.data, self.total.ctypes.data, self.depth.ctypes.data,
+                self.done.ctypes.data, self.legal.ctypes.data, self.tried.ctypes.data, self.nchild.ctypes.data,
+                self.child.ctypes.data, self.vmax.ctypes.data, self.prior_a.ctypes.data, self.rows.ctypes.data,
+                self.rows.shape[1], self.svec.ctypes.data, self.svec.shape[1], rel.ctypes.data, newid.ctypes.data))
+            return new_roots
         mark = np.zeros(self.n, dtype=bool)
         rel = np.zeros(self.n, dtype=np.int64)
         frontier = keep_roots[keep_roots >= 0]
