@@ -234,3 +234,48 @@ def test_gradient_matches_torch_autograd_batched(B, combo):
     for k, ref in grads.items():
         gs = max(float(ref.abs().max()), 1e-3 * gmax)
         assert np.abs(got[k] - ref.numpy()).max() <= 2e-4 * gs, k
+
+
+@pytest.mark.parametrize("case", [
+    dict(price="gru", process="gru", gas="gru", seq=(1, 2, 3), action_dim=3),
+    dict(price="gru", process="gru", gas="gru", seq=(32, 16, 7), action_dim=16),
+    dict(price="gru", process="gru", gas="gru", seq=(25, 10, 3), hidden_units=64, hidden_layers=3),
+    dict(price="conv", process="conv", gas="mlp", seq=(26, 1, 3), action_dim=7),
+    dict(price="transformer", process="gru", gas="mlp", seq=(32, 1, 3), act="tanh"),
+])
+def test_gradient_nonstandard_shapes(case):
+    """TD-loss gradient for window lengths at the ABI's limits, 1..16 actions and a head shape that takes the generic
+    head kernels, against autograd of the torch oracle (ragged batch of 21)."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.learner import DeviceLearner
+    case = dict(case)
+    seq = case.pop("seq")
+    cfg = {"act": "relu", "flavor": "per", "action_dim": 5, **case}
+    torch.manual_seed(13)
+    net, tgt = torch_ref.RefQNet(cfg), torch_ref.RefQNet(cfg)
+    spec = NetSpec(price=cfg["price"], process=cfg["process"], gas=cfg["gas"], act=cfg["act"],
+                   hidden_layers=cfg.get("hidden_layers", 2), hidden_units=cfg.get("hidden_units", 128),
+                   action_dim=cfg["action_dim"], seq=seq)
+    L = DeviceLearner(spec).load_state_dict({k: v.detach().numpy() for k, v in net.state_dict().items()},
+                                            {k: v.detach().numpy() for k, v in tgt.state_dict().items()})
+    B = 21
+    g = torch.Generator().manual_seed(2)
+    mk = lambda: (torch.rand(B, seq[0], 1, generator=g), torch.rand(B, seq[1], 6, generator=g), torch.rand(B, seq[2], 2, generator=g))
+    s, s2 = mk(), mk()
+    a = torch.randint(0, cfg["action_dim"], (B,), generator=g)
+    r, d = torch.rand(B, generator=g), (torch.rand(B, generator=g) < 0.2).float()
+    w = torch.rand(B, generator=g) * 0.9 + 0.1
+    with torch.no_grad():
+        y = r + 0.99 * tgt(*s2).max(1)[0] * (1 - d)
+    loss, td, grads = torch_ref.td_loss_and_grads(net, s, a, y, w)
+    batch = dict(sprice=s[0].cuda(), sprocess=s[1].cuda(), sgas=s[2].cuda(), nprice=s2[0].cuda(),
+                 nprocess=s2[1].cuda(), ngas=s2[2].cuda(), act=a.int().cuda(), rew=r.cuda(), done=d.cuda())
+    abs_td = L.compute_grad(batch, w.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(L.loss.item(), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(abs_td.cpu().numpy(), td.abs().numpy(), rtol=0, atol=2e-5)
+    got = spec.unpack(L.grad.cpu().numpy())
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    for k, ref in grads.items():
+        gs = max(float(ref.abs().max()), 1e-3 * gmax)
+        assert np.abs(got[k] - ref.numpy()).max() <= 2e-4 * gs, k

@@ -190,3 +190,47 @@ def test_self_preparing_entry_point_equals_prepared_one(name):
     torch.cuda.synchronize()
     assert torch.equal(q, ref["q"]) and torch.equal(vmax, ref["vmax"])
     assert torch.equal(arg, ref["argmax"]) and torch.equal(prior, ref["prior"])
+
+
+@pytest.mark.parametrize("case", [
+    dict(price="gru", process="gru", gas="gru", seq=(1, 1, 1), action_dim=5),                     # single-step windows
+    dict(price="gru", process="gru", gas="gru", seq=(2, 3, 2), action_dim=1),                     # one action
+    dict(price="gru", process="gru", gas="gru", seq=(32, 16, 7), action_dim=16),                  # longest windows the ABI accepts, 16 actions
+    dict(price="gru", process="gru", gas="gru", seq=(25, 10, 3), hidden_units=64, hidden_layers=3),   # generic head + per-encoder kernels
+    dict(price="conv", process="conv", gas="mlp", seq=(26, 1, 3), action_dim=7),                  # conv window limits
+    dict(price="conv", process="gru", gas="gru", seq=(2, 16, 5), act="tanh", action_dim=3),
+    dict(price="transformer", process="transformer", gas="gru", seq=(32, 1, 3), action_dim=9),    # attention tile limits
+    dict(price="transformer", process="conv", gas="mlp", seq=(17, 12, 3), hidden_layers=1),
+])
+def test_nonstandard_shapes_match_oracle(case):
+    """Window lengths at both ends of what the kernels stage (S = 1; GRU 32 x F<=4 and 16 x F>4, conv 26, transformer 32),
+    action counts 1..16, head shapes that take the generic head: all through the C ABI against the fp64 oracle, on a
+    ragged batch."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    case = dict(case)
+    seq = case.pop("seq")
+    cfg = {"act": "relu", "flavor": "per", **case}
+    cfg.setdefault("action_dim", 5)
+    torch.manual_seed(11)
+    ref_net = torch_ref.RefQNet(cfg)
+    sd = {k: v.detach().numpy() for k, v in ref_net.state_dict().items()}
+    spec = NetSpec(price=cfg["price"], process=cfg["process"], gas=cfg["gas"], act=cfg["act"],
+                   hidden_layers=cfg.get("hidden_layers", 2), hidden_units=cfg.get("hidden_units", 128),
+                   action_dim=cfg["action_dim"], seq=seq)
+    B = 37
+    g = torch.Generator().manual_seed(5)
+    x = [torch.rand(B, seq[0], 1, generator=g), torch.rand(B, seq[1], 6, generator=g), torch.rand(B, seq[2], 2, generator=g)]
+    ref64 = qnet_numpy.q_forward(sd, cfg, *[t.numpy() for t in x], np.float64)
+    net = DeviceQNet(spec).load_state_dict(sd)
+    out = net(*[t.cuda() for t in x])
+    q = out["q"].cpu().numpy()
+    scale = np.abs(ref64).max()
+    assert q.shape == ref64.shape
+    assert np.abs(q - ref64).max() <= 1e-5 * scale
+    srt = np.sort(ref64, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2e-5 * scale if ref64.shape[1] > 1 else np.ones(B, dtype=bool)
+    assert np.array_equal(out["argmax"].cpu().numpy()[clear], ref64.argmax(1)[clear])
+    p = out["prior"].cpu().numpy()
+    e = np.exp(ref64 - ref64.max(1, keepdims=True))
+    np.testing.assert_allclose(p, e / e.sum(1, keepdims=True), rtol=0, atol=2e-5)
