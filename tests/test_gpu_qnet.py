@@ -234,3 +234,20 @@ def test_nonstandard_shapes_match_oracle(case):
     p = out["prior"].cpu().numpy()
     e = np.exp(ref64 - ref64.max(1, keepdims=True))
     np.testing.assert_allclose(p, e / e.sum(1, keepdims=True), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["gru_gru_gru_per_relu", "conv_conv_mlp_per_relu", "transformer_transformer_gru_per_relu"])
+def test_empty_batch_and_bad_arguments(name):
+    """B = 0 is a no-op that returns empty outputs; a wrong window length is refused with a message, not launched."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd._lib import MctsqError
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, f"qnet_{name}.npz"))
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    out = net(torch.empty(0, 25, 1).cuda(), torch.empty(0, 10, 6).cuda(), torch.empty(0, 3, 2).cuda())
+    torch.cuda.synchronize()
+    assert out["q"].shape == (0, 5) and out["vmax"].shape == (0,)
+    with pytest.raises((MctsqError, ValueError)):
+        net(torch.rand(4, 24, 1).cuda(), torch.rand(4, 10, 6).cuda(), torch.rand(4, 3, 2).cuda())
+    with pytest.raises((MctsqError, ValueError)):
+        net(torch.rand(4, 25, 1).cuda(), torch.rand(3, 10, 6).cuda(), torch.rand(4, 3, 2).cuda())
