@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MCTSQ_ABI_VERSION 2
+#define MCTSQ_ABI_VERSION 3
 
 /* encoder kinds (dqn_per.py:181-203) */
 enum { MCTSQ_ENC_CONV = 1, MCTSQ_ENC_GRU = 2, MCTSQ_ENC_TRANSFORMER = 3, MCTSQ_ENC_MLP = 4 };
@@ -101,6 +101,18 @@ int mctsq_q_forward_prepared(const mctsq_net_desc* net, const float* d_params, c
                              const float* d_price, const float* d_process, const float* d_gas,
                              int64_t B, float* d_q, float* d_vmax, int32_t* d_argmax, float* d_prior,
                              void* d_ws, int64_t ws_bytes, void* stream, void* ev_encoders_done);
+
+/* ---- one encoder alone: ConvAttentionEnc / GRUAttentionEnc / TransformerEnc / GasEUAEncoder.forward
+ * (dqn_per.py:39-55, 66-77, 90-101, 122-130; module-level names of the reference boundary).
+ * d_enc_params holds ONLY that encoder's tensors, in its named_parameters() order and native torch layout,
+ * each tensor start padded to 16 floats: mctsq_encoder_param_layout fills offs/sizes (floats) and returns
+ * the tensor count.  d_x [B, seq_len, data_dim] fp32 -> d_out [B, 64] fp32.  MCTSQ_ENC_MLP is the gas/EUA
+ * Linear(3 F)-ReLU-Linear-ReLU block (seq_len must be 3).  d_ws: mctsq_encoder_workspace_bytes bytes. */
+int mctsq_encoder_param_layout(const mctsq_encoder_desc* enc, int64_t* offs, int64_t* sizes, int cap,
+                               int64_t* total);
+int64_t mctsq_encoder_workspace_bytes(const mctsq_encoder_desc* enc, int64_t B);
+int mctsq_encoder_forward(const mctsq_encoder_desc* enc, const float* d_enc_params, const float* d_x,
+                          int64_t B, float* d_out, void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- PER-DQN learner step on an already gathered batch: DQNModel.update (dqn_per.py:455-472)
  * = policy forward (activations kept), target forward + max, TD target and IS-weighted MSE,

@@ -37,6 +37,9 @@ SIGNATURES = {
     "mctsq_q_prepared_bytes": (_i64, [_ND]),
     "mctsq_q_prepare": (_i32, [_ND, _vp, _vp, _i64, _vp]),
     "mctsq_q_forward_prepared": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "mctsq_encoder_param_layout": (_i32, [C.POINTER(EncoderDesc), _vp, _vp, _i32, _vp]),
+    "mctsq_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderDesc), _i64]),
+    "mctsq_encoder_forward": (_i32, [C.POINTER(EncoderDesc), _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "mctsq_dqn_grad_workspace_bytes": (_i64, [_ND, _i64]),
     "mctsq_dqn_grad": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32,
                               _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

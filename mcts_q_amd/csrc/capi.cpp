@@ -440,3 +440,122 @@ int mctsq_per_gather(const float* d_states, const float* d_next_states, const in
 
 }  // extern "C"
 
+
+// ------------------------------------------------------------------------------- one encoder alone
+// ConvAttentionEnc / GRUAttentionEnc / TransformerEnc / GasEUAEncoder as stand-alone modules (dqn_per.py:21-130).
+// The encoder is placed in a slot of an otherwise minimal network layout (slot 0, or slot 2 for the gas/EUA MLP
+// whose Linear(3 F) is only defined there); its own tensors are then a contiguous, 16-float aligned run of that
+// layout, so a buffer that holds just them is addressed as `params - base`.  Only that slot's kernels are launched.
+namespace {
+struct SoloEnc {
+    NetLayout L;
+    int slot;
+    int first, count;          // tensors of the slot inside L.t_off / L.t_size
+    int64_t base, total;       // floats
+};
+int solo_layout(const mctsq_encoder_desc* enc, SoloEnc* S) {
+    MCTSQ_CHECK(enc != nullptr, "encoder descriptor is NULL");
+    mctsq_net_desc nd;
+    memset(&nd, 0, sizeof(nd));
+    const mctsq_encoder_desc dummy = {MCTSQ_ENC_GRU, 1, 1, MCTSQ_TF_NONE};
+    S->slot = enc->kind == MCTSQ_ENC_MLP ? 2 : 0;
+    for (int s = 0; s < 3; ++s) nd.enc[s] = s == S->slot ? *enc : dummy;
+    nd.embed_dim = E; nd.hidden_layers = 1; nd.hidden_units = 16; nd.action_dim = 1; nd.activation = MCTSQ_ACT_RELU;
+    if (build_layout(&nd, &S->L)) return -1;
+    const int per_kind = enc->kind == MCTSQ_ENC_TRANSFORMER ? 29 : enc->kind == MCTSQ_ENC_MLP ? 4 : 8;
+    S->first = S->slot == 0 ? 0 : 16;                     // two dummy GRU slots of 8 tensors precede slot 2
+    S->count = per_kind;
+    S->base = S->L.t_off[S->first];
+    S->total = S->L.t_off[S->first + per_kind] - S->base; // the next tensor (dummy slot / head) starts 16-aligned
+    return 0;
+}
+int64_t solo_prep_bytes(int kind) {
+    return kind == MCTSQ_ENC_GRU ? GRU_PREP_BYTES : kind == MCTSQ_ENC_CONV ? CONV_PREP_BYTES
+         : kind == MCTSQ_ENC_TRANSFORMER ? 2 * TF_LAYER_PREP_BYTES : 0;
+}
+int64_t solo_ws_floats(const SoloEnc& S, int64_t Bp) {
+    const EncOff& e = S.L.enc[S.slot];
+    int64_t n = Bp * FEAT;
+    if (e.kind == MCTSQ_ENC_TRANSFORMER) n += 2 * tf_padded_tokens(Bp, e.S) * E;
+    return round_up(n, 64) + solo_prep_bytes(e.kind) / (int64_t)sizeof(float);
+}
+}  // namespace
+
+extern "C" {
+
+int mctsq_encoder_param_layout(const mctsq_encoder_desc* enc, int64_t* offs, int64_t* sizes, int cap, int64_t* total) {
+    SoloEnc S;
+    if (solo_layout(enc, &S)) return -1;
+    for (int i = 0; i < S.count && i < cap; ++i) {
+        if (offs) offs[i] = S.L.t_off[S.first + i] - S.base;
+        if (sizes) sizes[i] = S.L.t_size[S.first + i];
+    }
+    if (total) *total = S.total;
+    return S.count;
+}
+
+int64_t mctsq_encoder_workspace_bytes(const mctsq_encoder_desc* enc, int64_t B) {
+    SoloEnc S;
+    if (solo_layout(enc, &S)) return -1;
+    if (B < 0) { set_error("negative batch"); return -1; }
+    return solo_ws_floats(S, round_up(B > 0 ? B : 1, TILE)) * (int64_t)sizeof(float);
+}
+
+int mctsq_encoder_forward(const mctsq_encoder_desc* enc, const float* d_enc_params, const float* d_x, int64_t B,
+                          float* d_out, void* d_ws, int64_t ws_bytes, void* stream) {
+    SoloEnc S;
+    if (solo_layout(enc, &S)) return -1;
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_enc_params && d_x && d_out, "NULL device pointer");
+    const int64_t Bp = round_up(B, TILE);
+    MCTSQ_CHECK(d_ws && ws_bytes >= solo_ws_floats(S, Bp) * (int64_t)sizeof(float), "workspace too small (%lld bytes)",
+                (long long)ws_bytes);
+    MCTSQ_CHECK(((uintptr_t)d_ws & 15) == 0 && ((uintptr_t)d_enc_params & 15) == 0,
+                "workspace and parameters must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const NetLayout& L = S.L;
+    const EncOff& e = L.enc[S.slot];
+    const float* params = d_enc_params - S.base;
+    float* ws = (float*)d_ws;
+    float* feats = ws;
+    float* hbuf = ws + Bp * FEAT;
+    char* prep = (char*)(ws + solo_ws_floats(S, Bp)) - solo_prep_bytes(e.kind);
+    const float* x[3] = {nullptr, nullptr, nullptr};
+    x[S.slot] = d_x;
+    if (e.kind == MCTSQ_ENC_GRU) {
+        const float* whh[3] = {params + e.gru.whh, nullptr, nullptr};
+        if (launch_gru_prepare(whh, 1, prep, st)) return -1;
+        GruFwdArgs ga;
+        fill_gru_args(ga, L, params, nullptr, x, B, Bp, feats, nullptr);   // fills all three GRU slots ...
+        ga.nslots = 1;                                                     // ... of which only the first is real
+        ga.slot[0].wprep = prep;
+        if (launch_gru_fwd(ga, false, st)) return -1;
+    } else if (e.kind == MCTSQ_ENC_CONV) {
+        const float* w2[2] = {params + e.conv.w2, nullptr};
+        if (launch_conv_prepare(w2, 1, prep, st)) return -1;
+        ConvFwdArgs ca;
+        fill_conv_args(ca, L, params, nullptr, x, B, Bp, feats, nullptr);
+        ca.slot[0].wprep = prep;
+        if (launch_conv_fwd(ca, false, st)) return -1;
+    } else if (e.kind == MCTSQ_ENC_TRANSFORMER) {
+        TfArgs t;
+        fill_tf_args(t, e, params, d_x, 0, B, Bp, feats, hbuf, nullptr);
+        for (int l = 0; l < 2; ++l) {
+            const TfLayerOff& o = e.tfm.layer[l];
+            char* p = prep + l * TF_LAYER_PREP_BYTES;
+            if (launch_tf_prepare(params + o.l1w, params + o.l2w, params + o.inw, params + o.ow, p, st)) return -1;
+            t.ffn_prep[l] = p;
+        }
+        if (launch_tf_fwd(t, st)) return -1;
+    } else {
+        MlpArgs ma;
+        if (!fill_mlp_args(ma, L, params, x, B, Bp, feats, nullptr)) { set_error("internal: mlp slot"); return -1; }
+        if (launch_mlp_fwd(ma, false, st)) return -1;
+    }
+    MCTSQ_HIP(hipMemcpy2DAsync(d_out, E * sizeof(float), feats + S.slot * E, FEAT * sizeof(float), E * sizeof(float),
+                               (size_t)B, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // extern "C"

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     dll = ctypes.CDLL(_lib.LIB_PATH)
     missing = [n for n in names if not hasattr(dll, n)]
     assert not missing, missing
-    assert dll.mctsq_abi_version() == 2
+    assert dll.mctsq_abi_version() == 3
 
 
 def test_ctypes_table_matches_header():
@@ -48,3 +48,20 @@ def test_host_tree_helper_exports_its_header():
     assert names == ["mctsq_tree_backup", "mctsq_tree_retain", "mctsq_tree_select"]
     dll = ctypes.CDLL(os.path.join(ROOT, "mcts_q_amd", "lib", "libmctsq_tree.so"))
     assert all(hasattr(dll, n) for n in names)
+
+
+def test_encoder_layout_query_needs_no_gpu():
+    """mctsq_encoder_param_layout: the stand-alone encoders' tensors in named_parameters() order."""
+    import numpy as np
+    lib = _lib.lib
+    for kind, S, F, count, total_min in ((1, 25, 1, 8, 64 * 3 + 64 * 64 * 3), (2, 10, 6, 8, 192 * 6 + 192 * 64),
+                                         (3, 10, 6, 29, 500 * 64 + 2 * 2 * 2048 * 64), (4, 3, 2, 4, 64 * 6 + 64 * 64)):
+        d = _lib.EncoderDesc(kind, S, F, 0)
+        offs, sizes, total = np.zeros(32, np.int64), np.zeros(32, np.int64), ctypes.c_int64(0)
+        n = lib.mctsq_encoder_param_layout(ctypes.byref(d), offs.ctypes.data, sizes.ctypes.data, 32, ctypes.addressof(total))
+        assert n == count and offs[0] == 0 and total.value >= total_min
+        assert all(o % 16 == 0 for o in offs[:n]) and all(offs[i] + sizes[i] <= offs[i + 1] for i in range(n - 1))
+        assert offs[n - 1] + sizes[n - 1] <= total.value
+        assert lib.mctsq_encoder_workspace_bytes(ctypes.byref(d), 100) >= 112 * 192 * 4
+    bad = _lib.EncoderDesc(4, 5, 2, 0)                       # mlp needs seq_len 3
+    assert lib.mctsq_encoder_workspace_bytes(ctypes.byref(bad), 4) < 0

@@ -19,11 +19,6 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _trainable(cfg):
-    from mcts_q_amd.capabilities import TRAIN_KINDS
-    return all(cfg[k] in TRAIN_KINDS for k in ("price", "process", "gas"))
-
-
 def _sd(z, cfg):
     sd = {k[3:]: z[k] for k in z.files if k.startswith("sd/")}
     if not sd:
@@ -48,8 +43,6 @@ def test_td_gradient_matches_reference_golden(path):
     from mcts_q_amd.learner import DeviceLearner
     z = np.load(path)
     cfg = json.loads(str(z["cfg"]))
-    if not _trainable(cfg):
-        pytest.skip("encoder kind not built for training yet")
     spec = NetSpec.from_cfg(cfg)
     L = DeviceLearner(spec).load_state_dict(_sd(z, cfg))
     dev = {k: torch.from_numpy(z[k]).cuda() for k in ("price", "process", "gas")}
@@ -120,8 +113,6 @@ def test_full_update_matches_reference_golden(path):
     from mcts_q_amd.per import DevicePER
     z = np.load(path)
     cfg = json.loads(str(z["cfg"]))
-    if not _trainable(cfg):
-        pytest.skip("encoder kind not built for training yet")
     spec = NetSpec.from_cfg(cfg)
     pre = {k[7:]: z[k] for k in z.files if k.startswith("sd_pre/")}
     tpre = {k[8:]: z[k] for k in z.files if k.startswith("tgt_pre/")}

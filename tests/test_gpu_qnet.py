@@ -13,12 +13,6 @@ from oracle import qnet_numpy, torch_ref
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-BUILT_KINDS = None
-
-
-def _supported(cfg):
-    from mcts_q_amd.capabilities import supported_kinds
-    return all(cfg[k] in supported_kinds() for k in ("price", "process", "gas"))
 
 
 def _load(path):
@@ -39,8 +33,6 @@ def test_forward_matches_reference_golden(path):
     from mcts_q_amd import NetSpec
     from mcts_q_amd.qnet import DeviceQNet
     z, cfg, sd = _load(path)
-    if not _supported(cfg):
-        pytest.skip("encoder kind not built yet")
     net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
     dev = [torch.from_numpy(z[k]).cuda() for k in ("price", "process", "gas")]
     out = net(*dev)
@@ -61,8 +53,6 @@ def test_forward_matches_oracle_batched(combo, B):
     from mcts_q_amd import NetSpec
     from mcts_q_amd.qnet import DeviceQNet
     z, cfg, sd = _load(os.path.join(GOLDEN, "qnet_%s_%s_%s_per_relu.npz" % combo))
-    if not _supported(cfg):
-        pytest.skip("encoder kind not built yet")
     g = torch.Generator().manual_seed(B)
     price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
         torch.rand(B, 3, 2, generator=g)
