@@ -61,7 +61,7 @@ def seeded_net(cfg, seed=3654):
     return net, {k: v.detach().numpy() for k, v in net.state_dict().items()}
 
 
-def cpu_baseline(cfg, ref_net, B, train_B, budget_s=20.0):
+def cpu_baseline(cfg, ref_net, B, train_B, replay_entries, budget_s=20.0):
     """Torch-CPU oracle (the arithmetic the reference runs) on the host cores: batched forwards at
     the GPU's batch size, the as-called pattern (one leaf per call, mcts_per.py:367-370), and a
     few full PER-DQN updates at the train batch size."""
@@ -83,10 +83,10 @@ def cpu_baseline(cfg, ref_net, B, train_B, budget_s=20.0):
             ref_net(p1, q1, g1).max().item(); n1 += 1
         single = n1 / (time.perf_counter() - t0)
     # train: reference formulation of PER sampling over N priorities + one update, torch CPU
-    N = 100_000
+    N = replay_entries                      # same replay size as the GPU side (BASELINE config 3: 1M entries)
     rng = np.random.RandomState(3654)
     prio = np.abs(rng.standard_normal(N))
-    rows, nrows = rng.random_sample((N, 91)).astype(np.float32), rng.random_sample((N, 91)).astype(np.float32)
+    rows, nrows = rng.random_sample((N, 91), ).astype(np.float32), rng.random_sample((N, 91)).astype(np.float32)
     acts, rews = rng.randint(0, 5, N), rng.random_sample(N).astype(np.float32)
     tgt = torch_ref.RefQNet.from_state_dict(cfg, {k: v.detach().numpy() for k, v in ref_net.state_dict().items()})
     net = torch_ref.RefQNet.from_state_dict(cfg, {k: v.detach().numpy() for k, v in ref_net.state_dict().items()})
@@ -110,14 +110,40 @@ def cpu_baseline(cfg, ref_net, B, train_B, budget_s=20.0):
             "as_called_b1_evals_per_s": single, "train_steps_per_s": 1.0 / float(np.median(tt))}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (collected offline with
-    tools/profile_bench.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    return None
+def profile_numbers():
+    """Numbers that need rocprofv3 and therefore come from committed profiles of this same command
+    (tools/profile_bench.sh), newest round first: HBM bytes per launch of the dominant kernel from the PMC passes
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) and the share of SIMD time its matrix pipe is busy."""
+    out = {"traffic": None, "traffic_source": None, "mfma_busy": None, "mfma_busy_source": None}
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if out["traffic"] is None and os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            out["traffic"] = d.get("hbm_bytes_per_launch")
+            out["traffic_source"] = f"profiles/{rnd}_pmc_traffic.json"
+        path = os.path.join(ROOT, "profiles", f"{rnd}_sq_counters.json")
+        if out["mfma_busy"] is None and os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            out["mfma_busy"] = d.get("mfma_busy_frac")
+            out["mfma_busy_source"] = f"profiles/{rnd}_sq_counters.json"
+    return out
+
+
+BF16_MATRIX_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
+
+
+def executed_pipe_peak(spec):
+    """Ceiling of the instructions the kernel actually issues, in fp32-equivalent TFLOP/s: the recurrent products and
+    the head run as SIX bf16 MFMAs per fp32 product (2500 / 6 = 417), the input projections as fp32 MFMA (157.3);
+    the two shares are weighted by the time each would take at its own peak."""
+    enc, head = forward_flops(spec)
+    fp32 = sum(S * 2 * 192 * F for kind, S, F in zip((spec.price, spec.process, spec.gas), spec.seq, spec.feat_dims)
+               if kind == "gru")
+    total = enc + head
+    fb = (total - fp32) / total
+    return 1.0 / (fb / (BF16_MATRIX_PEAK_TFLOPS / 6.0) + (1.0 - fb) / FP32_MATRIX_PEAK_TFLOPS), fb
 
 
 def main():
@@ -142,8 +168,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) as a CHILD job, before
+        # anything in this process touches the GPU, and relay its one JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -210,22 +245,43 @@ def main():
     flops = (enc_fl + head_fl) * B
     achieved = flops / (k_ms * 1e-3) / 1e12
     alg_bytes = (91 * 4 + 5 * 4 + 4 + 4 + 5 * 4) * B             # windows in; Q, vmax, argmax, prior out
+    prof = profile_numbers()
+    pipe_peak, bf16_share = executed_pipe_peak(spec)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": prof["traffic"],
+                "traffic_source": prof["traffic_source"],
                 "kernel": "gru3_head_fwd_kernel<false>", "kernel_ms": k_ms, "flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_GBs_algorithmic": alg_bytes / (k_ms * 1e-3) / 1e9,
-                "note": "intensity ~2.5 kFLOP/B: matrix/vector issue bounds it, not HBM.  achieved = ALGORITHMIC fp32 "
-                        "FLOPs / time against the dense fp32 MFMA peak; the recurrent products and the head run "
-                        "as six bf16 MFMAs on an exact 3-way split of both operands (fp32-accurate, 6 x the executed "
-                        "matrix FLOPs at 16 x the rate), the input projections on v_mfma_f32_16x16x4_f32"}
+                "frac_executed_pipe": achieved / pipe_peak, "executed_pipe_peak": pipe_peak,
+                "bf16_split_share_of_flops": bf16_share,
+                "mfma_busy_measured": prof["mfma_busy"], "mfma_busy_source": prof["mfma_busy_source"],
+                "note": "intensity ~2.5 kFLOP/B: matrix/vector issue bounds it, not HBM.  `frac` = ALGORITHMIC fp32 "
+                        "FLOPs / time against the dense fp32 MFMA peak (157.3).  The recurrent products and the head "
+                        "execute as six bf16 MFMAs on an exact 3-way split of both operands (fp32-accurate), whose "
+                        "ceiling is 2500/6 = 417 TFLOP/s fp32-equivalent; `frac_executed_pipe` prices the kernel against "
+                        "that ceiling blended with the fp32-MFMA share (input projections)"}
+
+    # --- the same K steps with the D2H of value / greedy action inside the timed region -----------
+    va = torch.empty(2 * B, dtype=torch.float32, device=dev)            # vmax | argmax in one buffer: one copy
+    out_d = dict(q=out["q"], vmax=va[:B], argmax=va[B:].view(torch.int32), prior=out["prior"])
+    host_va = torch.empty(2 * B, dtype=torch.float32, pin_memory=True)
+    for _ in range(max(3, args.warmup // 4)):
+        net(price, process, gas, out=out_d)
+        host_va.copy_(va, non_blocking=True)
+    barrier()
+    t0d = time.perf_counter()
+    for _ in range(args.steps):
+        net(price, process, gas, out=out_d)
+        host_va.copy_(va, non_blocking=True)
+    barrier()
+    wall_d2h = max_over_ranks(time.perf_counter() - t0d)
 
     # --- PER-DQN train steps (config 3), data-parallel over ranks ---------------------------------
-    train = None
+    train = train_weak = None
     if not args.no_train:
         from mcts_q_amd.learner import DeviceLearner
         from mcts_q_amd.per import DevicePER
-        Bg = args.train_batch                     # GLOBAL batch: the shards are sampled as one buffer
         N = args.replay
         group = dist.group.WORLD if world > 1 else None
         L = DeviceLearner(spec, dev, process_group=group).load_state_dict(sd)
@@ -243,35 +299,59 @@ def main():
         buf.update_priorities(torch.arange(N, device=dev), torch.from_numpy(pr).to(dev))
         tsteps = max(10, min(args.steps, 100))
         twarm = max(3, min(args.warmup, 10))
-        # the SAME uniforms on every rank (shared seed): each rank serves the draws in its mass interval
-        u_all = torch.from_numpy(np.random.RandomState(3654).random_sample((tsteps + twarm, Bg))).to(dev)
 
-        def train_step(i):
-            if world == 1:
-                idx, phys, w = buf.sample_indices(u_all[i])
-            else:
-                smp = parallel.sharded_sample(buf, u_all[i], group)
-                idx, phys, w = smp["idx"], smp["phys"], smp["w"]
-            batch = buf.gather(phys)
-            abs_td = L.compute_grad(batch, w, global_batch=Bg)
-            L.apply_grad(tau=0.005)
-            buf.update_priorities(idx, abs_td)
+        def run_train(Bg, kind):
+            # the SAME uniforms on every rank (shared seed): each rank serves the draws in its mass interval
+            u_all = torch.from_numpy(np.random.RandomState(3654).random_sample((tsteps + twarm, Bg))).to(dev)
+            sampler = parallel.ShardedSampler(buf, group) if world > 1 else None
 
-        for i in range(twarm):
-            train_step(i)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(tsteps):
-            train_step(twarm + i)
-        barrier()
-        twall = max_over_ranks(time.perf_counter() - t0)
-        train = {"metric": "PER-DQN train steps/sec (gru/gru/gru, 1M-entry sum-tree replay per rank, "
-                           f"global batch {Bg})", "value": tsteps / twall, "unit": "train steps/s",
-                 "steps": tsteps, "warmup": twarm, "ms_per_step": twall / tsteps * 1e3,
-                 "global_batch": Bg, "replay_entries_per_gpu": N,
-                 "scaling": "strong (global batch fixed; replay shards sampled as one buffer, each rank "
-                            "back-propagates its own draws; one flat-gradient all-reduce)",
-                 "transitions_per_s": tsteps * Bg / twall, "loss_last": float(L.loss.item())}
+            def train_step(i):
+                if world == 1:
+                    batch, w, idx, _ = buf.sample_batch(u_all[i])          # sample + IS weights + gather: one launch
+                else:
+                    smp = sampler.sample(u_all[i])                         # no host read of device memory
+                    batch, w, idx = smp["batch"], smp["w"], smp["idx"]
+                abs_td = L.compute_grad(batch, w, global_batch=Bg)
+                L.apply_grad(tau=0.005)
+                buf.update_priorities(idx, abs_td)
+
+            for i in range(twarm):
+                train_step(i)
+            tev0, tev1 = HipEvent(), HipEvent()
+            barrier()
+            t0 = time.perf_counter()
+            tev0.record(stream)
+            for i in range(tsteps):
+                train_step(twarm + i)
+            tev1.record(stream)
+            barrier()
+            twall = max_over_ranks(time.perf_counter() - t0)
+            enc_fl, head_fl = forward_flops(spec)
+            step_flops = 4 * (enc_fl + head_fl) * Bg           # policy fwd + 2 x bwd + target fwd
+            rows = Bg if world == 1 else sampler.bcap
+            act_bytes = sum(S * rows * 64 * 4 * 5 for S in spec.seq)      # r, z, n, W_hn h, h per GRU step: written, read back
+            step_bytes = 2 * act_bytes + sum(S * rows * 256 * 4 * 2 for S in spec.seq) + 2 * 364 * rows + 16 * spec.n_flat * 4
+            ach = step_flops / (twall / tsteps) / 1e12
+            return {"metric": "PER-DQN train steps/sec (gru/gru/gru, 1M-entry sum-tree replay per rank, "
+                              f"global batch {Bg})", "value": tsteps / twall, "unit": "train steps/s",
+                    "steps": tsteps, "warmup": twarm, "ms_per_step": twall / tsteps * 1e3,
+                    "gpu_ms_per_step_events_rank0": tev0.elapsed_ms(tev1) / tsteps,
+                    "global_batch": Bg, "rows_per_rank": rows, "replay_entries_per_gpu": N,
+                    "scaling": kind, "transitions_per_s": tsteps * Bg / twall, "loss_last": float(L.loss.item()),
+                    "roofline": {"bound": "latency chain (64 tiles of 16 transitions on 256 CUs; see DESIGN 5b)",
+                                 "flops_per_step": step_flops, "achieved": ach, "unit": "TFLOP/s",
+                                 "peak": FP32_MATRIX_PEAK_TFLOPS, "frac": ach / FP32_MATRIX_PEAK_TFLOPS,
+                                 "frac_executed_pipe": ach / executed_pipe_peak(spec)[0],
+                                 "activation_record_bytes": act_bytes, "algorithmic_bytes_per_step": step_bytes,
+                                 "hbm_GBs_algorithmic": step_bytes / (twall / tsteps) / 1e9,
+                                 "hbm_frac": step_bytes / (twall / tsteps) / 1e9 / HBM_PEAK_GBS,
+                                 "per_kernel": "profiles/r02_train_step_gru_B1024_kernel_stats.csv (rocprofv3 of "
+                                               "tools/train_loop.py) and profiles/r02_pmc_traffic.json"}}
+
+        train = run_train(args.train_batch, "strong (global batch fixed; replay shards sampled as one buffer, each rank "
+                          "back-propagates its own draws; one flat-gradient all-reduce)" if world > 1 else "single GPU")
+        if world > 1:
+            train_weak = run_train(args.train_batch * world, "weak (global batch = %d x ranks)" % args.train_batch)
 
     # --- lock-step MCTS in situ (config 5 shape per rank: `trees` trees x 50 iterations, one leaf batch per
     # iteration, vectorised synthetic environment; search only, weights fixed) -----------------------------
@@ -313,14 +393,22 @@ def main():
                                    f"{B} price/process/gas windows per GPU", "encoders": "gru/gru/gru",
                        "batch_per_gpu": B, "parallelism": f"trees sharded over {world} GPU(s), no collective"},
             "gpu_ms_per_step_events": gpu_ms_total / args.steps,
+            "with_d2h_of_value_and_action": {"value": world * B * args.steps / wall_d2h, "unit": "leaf evals/s",
+                                             "ms_per_step": wall_d2h / args.steps * 1e3,
+                                             "note": "same K steps, each followed by one async D2H of vmax|argmax "
+                                                     "(32 KB) into pinned memory, copies inside the timed region"},
+            "collective_backend": (dist.get_backend() if world > 1 else None),
+            "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
             "roofline": roofline,
         }
         if train is not None:
             res["train"] = train
+        if train_weak is not None:
+            res["train_weak"] = train_weak
         if trees is not None:
             res["tree_search"] = trees
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, ref_net, B, args.train_batch)
+            res["cpu_baseline"] = cpu_baseline(cfg, ref_net, B, args.train_batch, args.replay)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -135,9 +135,10 @@ int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float
 
 /* ---- clip_grad_norm_(max_norm) + Adam.step + Polyak target update (dqn_per.py:471-472,
  * 510-516) over the flat buffers, n floats each.  step is 1-based.  tau < 0 skips the target
- * update; tau == 1 is the hard copy of mctsq_config_dqn.py:547.  d_ws: >= 8 KiB scratch.
+ * update; tau == 1 is the hard copy of mctsq_config_dqn.py:547.  d_ws: mctsq_optim_workspace_bytes() of scratch.
  * d_gnorm (optional) receives the pre-clip global L2 norm.  Hyper-parameters are doubles because
  * the reference's are Python floats: torch forms 1-beta in fp64 before rounding to fp32. */
+int64_t mctsq_optim_workspace_bytes(void);
 int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
                            float* d_target, int64_t n, int64_t step, double lr, double beta1,
                            double beta2, double eps, double max_norm, double tau, float* d_gnorm,
@@ -147,12 +148,20 @@ int mctsq_polyak(const float* d_params, float* d_target, int64_t n, double tau, 
 
 /* ---- prioritized replay: PrioritizedReplayBuffer (dqn_per.py:238-321) as a device-resident
  * ring + 64-ary integer sum-tree.  Logical index 0 is the OLDEST entry (deque(maxlen)).
- * Priorities are fp64; probability mass m = rint(prio^alpha * 2^shift) as uint64 (deterministic
- * pow) so tree sums are exact and order-independent.
+ * Priorities are fp64; probability mass m = rint(min(prio^alpha, 256) * 2^shift) as uint64 (deterministic
+ * pow) so tree sums are exact and order-independent.  LIMIT: prio^alpha is clamped at 256
+ * (|td| above ~1.03e4 at alpha = 0.6; the reference has no clamp, dqn_per.py:286-301) so that capacity * mass
+ * cannot overflow 64 bits; the importance weights are computed from the same clamped value, i.e. they stay the
+ * exact weights of the law that is actually sampled.
  *
  * The tree is one uint64 device array of mctsq_per_tree_words(capacity) words, caller-zeroed
  * before first use; d_prio is fp64 [capacity] in PHYSICAL slot order; head = physical slot of
- * logical index 0; size = live entries. */
+ * logical index 0; size = live entries.
+ *
+ * Workspace of the sampling calls (d_ws, mctsq_per_workspace_bytes(capacity, B) bytes, 16-byte aligned): its
+ * first 64 bytes are control words that must be ZERO when the buffer is first handed to the library and are
+ * left zero by every call; the caller keeps the buffer per replay ring and does not write to it.  Two sampling
+ * calls that share one workspace must not overlap in time. */
 int64_t mctsq_per_tree_words(int64_t capacity);
 int mctsq_per_mass_shift(int64_t capacity);
 /* mass_capacity (push / sample / update): the capacity the fixed-point scale is derived from -
@@ -165,19 +174,32 @@ int mctsq_per_mass_shift(int64_t capacity);
 int mctsq_per_push(uint64_t* d_tree, double* d_prio, const double* d_maxprio, int64_t capacity,
                    int64_t head, int64_t size, int64_t K, double alpha, int64_t mass_capacity,
                    void* stream);
-/* recompute *d_maxprio = max(prio[live]) (1.0 if empty): the O(N) max() of dqn_per.py:265. */
+/* recompute *d_maxprio = max(prio[live]) (1.0 if empty): the O(N) max() of dqn_per.py:265.  d_ws: the ring's
+ * sampling workspace (>= mctsq_per_workspace_bytes(capacity, 1) bytes; the control words are not touched). */
 int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, int64_t size,
                           double* d_maxprio, void* d_ws, int64_t ws_bytes, void* stream);
 /* sample (dqn_per.py:283-301): d_u fp64 [B] uniforms in [0,1) -> d_idx int64 [B] LOGICAL
  * indices, d_phys int64 [B] physical slots, d_w fp32 [B] IS weights (N p_i)^-beta / max.
- * d_wmax (optional, fp64 [1]) receives that max before normalisation. */
+ * d_wmax (optional, fp64 [1]) receives that max before normalisation.  One launch for B <= 16384. */
 int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
                      int64_t size, const double* d_u, int64_t B, double alpha, double beta,
                      int64_t mass_capacity, int64_t* d_idx, int64_t* d_phys, float* d_w,
                      double* d_wmax, void* d_ws, int64_t ws_bytes, void* stream);
+/* mctsq_per_sample and mctsq_per_gather in ONE launch (dqn_per.py:283-305 + the batch assembly of
+ * :415-452): the wave that finds a slot also copies its transition into the learner's batch tensors. */
+int mctsq_per_sample_batch(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
+                           int64_t size, const double* d_u, int64_t B, double alpha, double beta,
+                           int64_t mass_capacity, int64_t* d_idx, int64_t* d_phys, float* d_w,
+                           double* d_wmax, const float* d_states, const float* d_next_states,
+                           const int32_t* d_actions, const float* d_rewards, const float* d_dones,
+                           float* d_sprice, float* d_sprocess, float* d_sgas, float* d_nprice,
+                           float* d_nprocess, float* d_ngas, int32_t* d_act, float* d_rew, float* d_done,
+                           void* d_ws, int64_t ws_bytes, void* stream);
 /* update_priorities (dqn_per.py:307-314): prio[idx[i]] = p[i] sequentially (last duplicate
  * wins); d_idx LOGICAL int64 [B], d_newprio fp32 [B].  d_stamp: int32 [capacity] scratch owned by
- * the buffer, all -1 on entry (the call leaves it all -1 again). */
+ * the buffer, all -1 on entry (the call leaves it all -1 again).  Indices outside [0, size) name no stored
+ * transition and are ignored (the reference raises IndexError; host-side callers check before calling).
+ * One launch for B <= 4096. */
 int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t capacity,
                      int64_t head, int64_t size, const int64_t* d_idx, const float* d_newprio,
                      int64_t B, double alpha, int64_t mass_capacity, void* stream);
@@ -185,13 +207,15 @@ int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t
 /* ---- sharded replay (no reference counterpart: SURVEY.md section 8e).  W ranks each own one ring;
  * together they are sampled as ONE buffer whose logical order is the concatenation of the shards
  * in rank order, with the same exact-integer inverse CDF:
- *   1. every rank: mctsq_per_total_mass -> its root mass; all-gather the W masses (and sizes);
+ *   1. every rank: mctsq_per_total_mass -> d_mass[0] = its root mass, d_mass[1] = size (the pair the ranks
+ *      all-gather, produced on the device so that no host value has to be copied in);
  *   2. every rank: mctsq_per_shard_targets on the SAME B uniforms -> which draws fall into its
  *      interval of the concatenated mass line (d_mine) and their local integer targets;
  *   3. compact its own draws, mctsq_per_sample_at with n_total / mass_total of the whole buffer
  *      -> local indices, raw fp64 IS weights and their local max;
  *   4. all-reduce(MAX) the max, mctsq_per_normalize_weights -> fp32 weights. */
-int mctsq_per_total_mass(const uint64_t* d_tree, int64_t capacity, uint64_t* d_mass, void* stream);
+int mctsq_per_total_mass(const uint64_t* d_tree, int64_t capacity, int64_t size, uint64_t* d_mass,
+                         void* stream);
 int mctsq_per_shard_targets(const double* d_u, int64_t B, const uint64_t* d_shard_mass, int world,
                             int rank, uint64_t* d_targets, int32_t* d_mine, void* stream);
 int mctsq_per_sample_at(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
@@ -200,6 +224,27 @@ int mctsq_per_sample_at(const uint64_t* d_tree, const double* d_prio, int64_t ca
                         int64_t* d_phys, double* d_w64, double* d_wmax, void* stream);
 int mctsq_per_normalize_weights(const double* d_w64, int64_t B, const double* d_wmax, float* d_w,
                                 void* stream);
+/* The same protocol WITHOUT host round trips (steps 2-3 above need the number of own draws on the host):
+ *   mctsq_per_shard_select: the rank's draws compacted to the front of d_targets [bcap] (draw order kept),
+ *     d_draw [bcap] = their positions in d_u (-1 = padding), d_count[0] = how many, d_count[1] = how many did
+ *     NOT fit bcap (must be 0: the caller sizes bcap for its share of the batch and checks this word lazily);
+ *   mctsq_per_sample_shard: bcap rows from those targets with the totals of the whole buffer read from the
+ *     all-gathered DEVICE arrays d_shard_mass / d_shard_size [world]; rows >= d_count[0] are padding
+ *     (d_idx = -1, d_phys = 0, weight 0: they contribute exactly nothing to loss, gradient and priorities);
+ *     also gathers the transitions like mctsq_per_sample_batch.  d_wmax = local max of the raw weights. */
+int mctsq_per_shard_select(const double* d_u, int64_t B, const uint64_t* d_shard_mass, int world, int rank,
+                           int64_t bcap, uint64_t* d_targets, int32_t* d_draw, int32_t* d_count,
+                           void* stream);
+int mctsq_per_sample_shard(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
+                           int64_t size, const uint64_t* d_targets, const int32_t* d_count, int64_t bcap,
+                           double alpha, double beta, int64_t mass_capacity,
+                           const uint64_t* d_shard_mass, const int64_t* d_shard_size, int world,
+                           int64_t* d_idx, int64_t* d_phys, double* d_w64, double* d_wmax,
+                           const float* d_states, const float* d_next_states, const int32_t* d_actions,
+                           const float* d_rewards, const float* d_dones, float* d_sprice,
+                           float* d_sprocess, float* d_sgas, float* d_nprice, float* d_nprocess,
+                           float* d_ngas, int32_t* d_act, float* d_rew, float* d_done, void* d_ws,
+                           int64_t ws_bytes, void* stream);
 /* gather the sampled transitions (dqn_per.py:293, 415-452): rows are 96-float padded
  * [price 25 | process 10x6 | gas 3x2 | pad] records; outputs are the six window tensors the
  * learner consumes plus actions / rewards / dones. */

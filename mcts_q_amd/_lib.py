@@ -43,6 +43,7 @@ SIGNATURES = {
     "mctsq_dqn_grad_workspace_bytes": (_i64, [_ND, _i64]),
     "mctsq_dqn_grad": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32,
                               _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mctsq_optim_workspace_bytes": (_i64, []),
     "mctsq_clip_adam_polyak": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64,
                                       _f64, _vp, _vp, _i64, _vp]),
     "mctsq_polyak": (_i32, [_vp, _vp, _i64, _f64, _vp]),
@@ -53,8 +54,13 @@ SIGNATURES = {
     "mctsq_per_refresh_max": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
     "mctsq_per_sample": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _i64, _vp, _vp, _vp, _vp, _vp,
                                 _i64, _vp]),
+    "mctsq_per_sample_batch": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _i64, _vp, _vp, _vp, _vp]
+                               + [_vp] * 14 + [_vp, _i64, _vp]),
+    "mctsq_per_shard_select": (_i32, [_vp, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "mctsq_per_sample_shard": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _f64, _f64, _i64, _vp, _vp, _i32,
+                                      _vp, _vp, _vp, _vp] + [_vp] * 14 + [_vp, _i64, _vp]),
     "mctsq_per_update": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _f64, _i64, _vp]),
-    "mctsq_per_total_mass": (_i32, [_vp, _i64, _vp, _vp]),
+    "mctsq_per_total_mass": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "mctsq_per_shard_targets": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp]),
     "mctsq_per_sample_at": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _i64, _f64, _f64, _vp, _vp,
                                    _vp, _vp, _vp]),

@@ -322,7 +322,8 @@ int mctsq_per_mass_shift(int64_t capacity) { return per_mass_shift(capacity); }
 
 int64_t mctsq_per_workspace_bytes(int64_t capacity, int64_t B) {
     (void)capacity;
-    const int64_t a = (B > 0 ? B : 1) * 8, b = 1024 * 8;
+    // control words + one raw fp64 weight per draw; never less than the 1024 partials of mctsq_per_refresh_max
+    const int64_t a = PER_WS_CTRL_BYTES + (B > 0 ? B : 1) * 8, b = PER_WS_CTRL_BYTES + 1024 * 8;
     return a > b ? a : b;
 }
 
@@ -353,9 +354,33 @@ int mctsq_per_push(uint64_t* d_tree, double* d_prio, const double* d_maxprio, in
 int mctsq_per_refresh_max(const double* d_prio, int64_t capacity, int64_t head, int64_t size, double* d_maxprio,
                           void* d_ws, int64_t ws_bytes, void* stream) {
     if (check_ring(capacity, head, size)) return -1;
-    MCTSQ_CHECK(d_prio && d_maxprio && d_ws && ws_bytes >= 1024 * 8, "NULL pointer or workspace < 8 KiB");
-    // live entries are physical [0, size) (ring not full) or all of [0, capacity)
-    return launch_per_refresh_max(d_prio, size, d_maxprio, (double*)d_ws, 1024, (hipStream_t)stream);
+    MCTSQ_CHECK(d_prio && d_maxprio && d_ws && ws_bytes >= PER_WS_CTRL_BYTES + 1024 * 8,
+                "NULL pointer or workspace smaller than mctsq_per_workspace_bytes(capacity, 1)");
+    // live entries are physical [0, size) (ring not full) or all of [0, capacity); the partials sit behind the
+    // control words of the sampling workspace, which this call leaves alone
+    return launch_per_refresh_max(d_prio, size, d_maxprio, (double*)((char*)d_ws + PER_WS_CTRL_BYTES), 1024,
+                                  (hipStream_t)stream);
+}
+
+static int fill_gather(PerGatherArgs& a, const float* d_states, const float* d_next_states, const int32_t* d_actions,
+                       const float* d_rewards, const float* d_dones, const int64_t* d_phys, int64_t B, float* d_sprice,
+                       float* d_sprocess, float* d_sgas, float* d_nprice, float* d_nprocess, float* d_ngas,
+                       int32_t* d_act, float* d_rew, float* d_done) {
+    MCTSQ_CHECK(d_states && d_next_states && d_actions && d_rewards && d_dones && d_phys && d_sprice &&
+                    d_sprocess && d_sgas && d_nprice && d_nprocess && d_ngas && d_act && d_rew && d_done,
+                "NULL device pointer");
+    a.states = d_states; a.next_states = d_next_states; a.actions = d_actions; a.rewards = d_rewards;
+    a.dones = d_dones; a.phys = d_phys; a.B = B;
+    a.sprice = d_sprice; a.sprocess = d_sprocess; a.sgas = d_sgas;
+    a.nprice = d_nprice; a.nprocess = d_nprocess; a.ngas = d_ngas;
+    a.act = d_act; a.rew = d_rew; a.done = d_done;
+    return 0;
+}
+
+static int check_sample_ws(const void* d_ws, int64_t ws_bytes, int64_t B) {
+    MCTSQ_CHECK(d_ws && ws_bytes >= PER_WS_CTRL_BYTES + B * 8, "workspace too small");
+    MCTSQ_CHECK(((uintptr_t)d_ws & 15) == 0, "workspace must be 16-byte aligned");
+    return 0;
 }
 
 int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
@@ -367,14 +392,67 @@ int mctsq_per_sample(const uint64_t* d_tree, const double* d_prio, int64_t capac
     MCTSQ_CHECK(B >= 0, "negative batch");
     if (B == 0) return 0;
     MCTSQ_CHECK(d_tree && d_prio && d_u && d_idx && d_phys && d_w, "NULL device pointer");
-    MCTSQ_CHECK(d_ws && ws_bytes >= B * 8, "workspace too small");
+    if (check_sample_ws(d_ws, ws_bytes, B)) return -1;
     return launch_per_sample((const unsigned long long*)d_tree, d_prio, capacity, head, size, d_u, B, alpha,
-                             beta, mass_capacity, d_idx, d_phys, d_w, d_wmax, (double*)d_ws, (hipStream_t)stream);
+                             beta, mass_capacity, d_idx, d_phys, d_w, d_wmax, d_ws, nullptr, (hipStream_t)stream);
 }
 
-int mctsq_per_total_mass(const uint64_t* d_tree, int64_t capacity, uint64_t* d_mass, void* stream) {
+int mctsq_per_sample_batch(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
+                           const double* d_u, int64_t B, double alpha, double beta, int64_t mass_capacity,
+                           int64_t* d_idx, int64_t* d_phys, float* d_w, double* d_wmax, const float* d_states,
+                           const float* d_next_states, const int32_t* d_actions, const float* d_rewards,
+                           const float* d_dones, float* d_sprice, float* d_sprocess, float* d_sgas, float* d_nprice,
+                           float* d_nprocess, float* d_ngas, int32_t* d_act, float* d_rew, float* d_done, void* d_ws,
+                           int64_t ws_bytes, void* stream) {
+    if (check_ring(capacity, head, size) || check_mass_cap(capacity, mass_capacity)) return -1;
+    MCTSQ_CHECK(size >= 1, "cannot sample from an empty buffer");
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_tree && d_prio && d_u && d_idx && d_phys && d_w, "NULL device pointer");
+    if (check_sample_ws(d_ws, ws_bytes, B)) return -1;
+    PerGatherArgs ga;
+    if (fill_gather(ga, d_states, d_next_states, d_actions, d_rewards, d_dones, d_phys, B, d_sprice, d_sprocess, d_sgas,
+                    d_nprice, d_nprocess, d_ngas, d_act, d_rew, d_done)) return -1;
+    return launch_per_sample((const unsigned long long*)d_tree, d_prio, capacity, head, size, d_u, B, alpha,
+                             beta, mass_capacity, d_idx, d_phys, d_w, d_wmax, d_ws, &ga, (hipStream_t)stream);
+}
+
+int mctsq_per_shard_select(const double* d_u, int64_t B, const uint64_t* d_shard_mass, int world, int rank,
+                           int64_t bcap, uint64_t* d_targets, int32_t* d_draw, int32_t* d_count, void* stream) {
+    MCTSQ_CHECK(B >= 0 && B < ((int64_t)1 << 31) && world >= 1 && world <= 64 && rank >= 0 && rank < world,
+                "bad shard geometry");
+    MCTSQ_CHECK(bcap >= 1, "per-rank draw capacity must be >= 1");
+    MCTSQ_CHECK((B == 0 || d_u) && d_shard_mass && d_targets && d_draw && d_count, "NULL device pointer");
+    return launch_per_shard_select(d_u, B, (const unsigned long long*)d_shard_mass, world, rank, bcap,
+                                   (unsigned long long*)d_targets, d_draw, d_count, (hipStream_t)stream);
+}
+
+int mctsq_per_sample_shard(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
+                           const uint64_t* d_targets, const int32_t* d_count, int64_t bcap, double alpha, double beta,
+                           int64_t mass_capacity, const uint64_t* d_shard_mass, const int64_t* d_shard_size, int world,
+                           int64_t* d_idx, int64_t* d_phys, double* d_w64, double* d_wmax, const float* d_states,
+                           const float* d_next_states, const int32_t* d_actions, const float* d_rewards,
+                           const float* d_dones, float* d_sprice, float* d_sprocess, float* d_sgas, float* d_nprice,
+                           float* d_nprocess, float* d_ngas, int32_t* d_act, float* d_rew, float* d_done, void* d_ws,
+                           int64_t ws_bytes, void* stream) {
+    if (check_ring(capacity, head, size) || check_mass_cap(capacity, mass_capacity)) return -1;
+    MCTSQ_CHECK(bcap >= 1 && world >= 1 && world <= 64, "bad shard geometry");
+    MCTSQ_CHECK(d_tree && d_prio && d_targets && d_count && d_shard_mass && d_shard_size && d_idx && d_phys && d_w64 &&
+                    d_wmax, "NULL device pointer");
+    if (check_sample_ws(d_ws, ws_bytes, 0)) return -1;
+    PerGatherArgs ga;
+    if (fill_gather(ga, d_states, d_next_states, d_actions, d_rewards, d_dones, d_phys, bcap, d_sprice, d_sprocess,
+                    d_sgas, d_nprice, d_nprocess, d_ngas, d_act, d_rew, d_done)) return -1;
+    return launch_per_sample_shard((const unsigned long long*)d_tree, d_prio, capacity, head, size,
+                                   (const unsigned long long*)d_targets, d_count, bcap, alpha, beta, mass_capacity,
+                                   (const unsigned long long*)d_shard_mass, d_shard_size, world, d_idx, d_phys, d_w64,
+                                   d_wmax, d_ws, &ga, (hipStream_t)stream);
+}
+
+int mctsq_per_total_mass(const uint64_t* d_tree, int64_t capacity, int64_t size, uint64_t* d_mass, void* stream) {
     MCTSQ_CHECK(d_tree && d_mass, "NULL device pointer");
-    return launch_per_total_mass((const unsigned long long*)d_tree, capacity, (unsigned long long*)d_mass,
+    MCTSQ_CHECK(size >= 0 && size <= capacity, "size %lld outside [0, capacity]", (long long)size);
+    return launch_per_total_mass((const unsigned long long*)d_tree, capacity, size, (unsigned long long*)d_mass,
                                  (hipStream_t)stream);
 }
 
@@ -416,8 +494,8 @@ int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t
     if (B == 0) return 0;
     MCTSQ_CHECK(d_tree && d_prio && d_stamp && d_idx && d_newprio, "NULL device pointer");
     MCTSQ_CHECK(B < ((int64_t)1 << 31), "update batch too large");
-    return launch_per_update((unsigned long long*)d_tree, d_prio, d_stamp, capacity, head, d_idx, d_newprio, B, alpha,
-                             mass_capacity, (hipStream_t)stream);
+    return launch_per_update((unsigned long long*)d_tree, d_prio, d_stamp, capacity, head, size, d_idx, d_newprio, B,
+                             alpha, mass_capacity, (hipStream_t)stream);
 }
 
 int mctsq_per_gather(const float* d_states, const float* d_next_states, const int32_t* d_actions,
@@ -426,15 +504,9 @@ int mctsq_per_gather(const float* d_states, const float* d_next_states, const in
                      float* d_ngas, int32_t* d_act, float* d_rew, float* d_done, void* stream) {
     MCTSQ_CHECK(B >= 0, "negative batch");
     if (B == 0) return 0;
-    MCTSQ_CHECK(d_states && d_next_states && d_actions && d_rewards && d_dones && d_phys && d_sprice &&
-                    d_sprocess && d_sgas && d_nprice && d_nprocess && d_ngas && d_act && d_rew && d_done,
-                "NULL device pointer");
     PerGatherArgs a;
-    a.states = d_states; a.next_states = d_next_states; a.actions = d_actions; a.rewards = d_rewards;
-    a.dones = d_dones; a.phys = d_phys; a.B = B;
-    a.sprice = d_sprice; a.sprocess = d_sprocess; a.sgas = d_sgas;
-    a.nprice = d_nprice; a.nprocess = d_nprocess; a.ngas = d_ngas;
-    a.act = d_act; a.rew = d_rew; a.done = d_done;
+    if (fill_gather(a, d_states, d_next_states, d_actions, d_rewards, d_dones, d_phys, B, d_sprice, d_sprocess, d_sgas,
+                    d_nprice, d_nprocess, d_ngas, d_act, d_rew, d_done)) return -1;
     return launch_per_gather(a, (hipStream_t)stream);
 }
 

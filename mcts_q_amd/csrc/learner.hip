@@ -47,7 +47,7 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < 16; ++i) t += red[i];
-        *a.loss = (float)(t / (double)a.B);
+        *a.loss = (float)(t * a.loss_norm);
     }
 }
 

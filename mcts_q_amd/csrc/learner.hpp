@@ -15,6 +15,7 @@ struct TdArgs {
     const int32_t* act;
     const float *rew, *done, *isw;
     float gamma, grad_scale;    // grad_scale = loss_scale * 2 / B
+    double loss_norm;           // loss = loss_norm * sum w td^2, loss_norm = loss_scale / B
     int64_t B, Bp;
     int A;
     float* dq;                  // [Bp][16]

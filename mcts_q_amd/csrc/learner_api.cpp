@@ -5,7 +5,9 @@
 // joined to the caller's stream with events; everything else is enqueued on the caller's stream.
 #include <string.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "forward.hpp"
 #include "learner.hpp"
@@ -187,23 +189,23 @@ namespace {
 // The target forward (on s') and the policy forward (on s) are independent and each fills only part of
 // the chip at training batch sizes, so they run side by side: the target network goes to a helper
 // stream forked from / joined to the caller's stream with events (no host synchronisation; the pattern
-// is also legal under stream capture).  One helper stream and event pair per device, created on first
-// use and kept for the life of the process.
+// is also legal under stream capture).  One helper stream and event pair per (device, caller stream),
+// created on first use and kept for the life of the process, so calls on different streams never share
+// events; calls on the SAME stream are ordered by the caller (one host thread enqueues on a stream at a time).
 struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 std::mutex g_side_mu;
-SideStream g_side[64];
-int side_stream(SideStream** out) {
+std::map<std::pair<int, void*>, SideStream> g_side;
+int side_stream(hipStream_t caller, SideStream* out) {
     int dev = 0;
     MCTSQ_HIP(hipGetDevice(&dev));
-    MCTSQ_CHECK(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
     std::lock_guard<std::mutex> lk(g_side_mu);
-    SideStream& s = g_side[dev];
+    SideStream& s = g_side[std::make_pair(dev, (void*)caller)];
     if (!s.st) {
         MCTSQ_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
     }
-    *out = &s;
+    *out = s;
     return 0;
 }
 }  // namespace
@@ -216,6 +218,13 @@ extern "C" int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int
     if (make_plan(L, B, &P)) return -1;
     return P.total * (int64_t)sizeof(float);
 }
+
+static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideStream* side, const float* d_params,
+                            const float* d_target_params, const float* d_sprice, const float* d_sprocess,
+                            const float* d_sgas, const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                            const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
+                            float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss, float* d_abs_td,
+                            float* d_qsa, float* d_target, float* ws, hipStream_t st);
 
 extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
                               const float* d_sprice, const float* d_sprocess, const float* d_sgas,
@@ -236,15 +245,30 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
                 (long long)ws_bytes, (long long)(P.total * (int64_t)sizeof(float)));
     MCTSQ_CHECK(((uintptr_t)d_ws & 15) == 0, "workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    float* ws = (float*)d_ws;
+    SideStream side;
+    if (side_stream(st, &side)) return -1;
+    MCTSQ_HIP(hipEventRecord(side.fork, st));
+    MCTSQ_HIP(hipStreamWaitEvent(side.st, side.fork, 0));
+    const int rc = dqn_grad_enqueue(L, P, &side, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice,
+                                    d_nprocess, d_ngas, d_act, d_rew, d_done, d_isw, gamma, loss_scale, B, d_grad,
+                                    d_loss, d_abs_td, d_qsa, d_target, (float*)d_ws, st);
+    if (rc != 0) {                     // whatever was enqueued on the helper stream is joined back before returning
+        hipEventRecord(side.join, side.st);
+        hipStreamWaitEvent(st, side.join, 0);
+    }
+    return rc;
+}
+
+static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideStream* side, const float* d_params,
+                            const float* d_target_params, const float* d_sprice, const float* d_sprocess,
+                            const float* d_sgas, const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                            const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
+                            float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss, float* d_abs_td,
+                            float* d_qsa, float* d_target, float* ws, hipStream_t st) {
     const int64_t Bp = P.Bp;
 
-    // 1. target network on s' -> max_a' Q (dqn_per.py:460-463), on the helper stream
-    SideStream* side = nullptr;
-    if (side_stream(&side)) return -1;
+    // 1. target network on s' -> max_a' Q (dqn_per.py:460-463), on the helper stream (forked by the caller)
     {
-        MCTSQ_HIP(hipEventRecord(side->fork, st));
-        MCTSQ_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
         // the flat gradient's alignment pads must read zero; nothing touches it before the ordered reduction (step 7,
         // behind the join), so the fill rides on the helper stream instead of the critical path
         MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
@@ -308,6 +332,7 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
         memset(&t, 0, sizeof(t));
         t.q = ws + P.q_p; t.qnext = ws + P.qnext; t.act = d_act; t.rew = d_rew; t.done = d_done; t.isw = d_isw;
         t.gamma = gamma; t.grad_scale = loss_scale * 2.0f / (float)B; t.B = B; t.Bp = Bp; t.A = L.A;
+        t.loss_norm = (double)loss_scale / (double)B;
         t.dq = ws + P.dq; t.loss = d_loss; t.abs_td = d_abs_td; t.qsa = d_qsa; t.target = d_target;
         if (launch_td_loss(t, st)) return -1;
     }

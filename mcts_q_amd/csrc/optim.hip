@@ -31,9 +31,30 @@ struct AdamArgs {
     float* gnorm_out;
 };
 
+// FUSED_NORM: every block computes the global sum of squares itself, all in the same fixed order (thread t takes
+// the float4s t, t + 256, ...; wave shuffle; four wave sums), instead of reading partials a separate launch made:
+// for a parameter buffer that sits in L2 the redundant read costs ~1 us and saves a launch on the step's chain.
+constexpr int64_t FUSED_NORM_MAX = 1 << 18;        // floats (1 MB): gru/gru/gru and conv/conv/mlp networks
+template <bool FUSED_NORM>
 __global__ __launch_bounds__(256) void clip_adam_polyak_kernel(AdamArgs a) {
     __shared__ float s_coef;
-    if (threadIdx.x < 64) {                       // every block folds the same 256 partials, same order
+    __shared__ double s_red[4];
+    if (FUSED_NORM) {
+        const int64_t n4 = a.n >> 2;
+        double acc = 0.0;
+        for (int64_t i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = reinterpret_cast<const float4*>(a.g)[i];
+            acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float total = (float)sqrt((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+            s_coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
+            if (blockIdx.x == 0 && a.gnorm_out) *a.gnorm_out = total;
+        }
+    } else if (threadIdx.x < 64) {                // every block folds the same 256 partials, same order
         double acc = 0.0;
         for (int i = threadIdx.x; i < NPART; i += 64) acc += a.part[i];
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
@@ -98,6 +119,8 @@ static unsigned stream_grid(int64_t n4) {
 
 using namespace mctsq;
 
+extern "C" int64_t mctsq_optim_workspace_bytes(void) { return (int64_t)(NPART * sizeof(double)); }
+
 extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
                                       float* d_target, int64_t n, int64_t step, double lr, double beta1,
                                       double beta2, double eps, double max_norm, double tau, float* d_gnorm,
@@ -105,10 +128,11 @@ extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, floa
     MCTSQ_CHECK(d_params && d_grad && d_m && d_v, "NULL device pointer");
     MCTSQ_CHECK(n > 0 && n % 16 == 0, "flat buffer length must be a positive multiple of 16 (padded layout)");
     MCTSQ_CHECK(step >= 1, "Adam step is 1-based");
-    MCTSQ_CHECK(d_ws && ws_bytes >= (int64_t)(NPART * sizeof(double)), "workspace must be >= 8 KiB");
+    MCTSQ_CHECK(d_ws && ws_bytes >= mctsq_optim_workspace_bytes(), "workspace must hold mctsq_optim_workspace_bytes()");
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)d_ws;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NPART), dim3(256), 0, st, d_grad, n, part);
+    const bool fused = n <= FUSED_NORM_MAX;
+    if (!fused) hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NPART), dim3(256), 0, st, d_grad, n, part);
     AdamArgs a;
     a.p = d_params; a.g = d_grad; a.m = d_m; a.v = d_v; a.tgt = tau >= 0.0 ? d_target : nullptr;
     a.n = n;
@@ -119,7 +143,8 @@ extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, floa
     a.eps = (float)eps; a.max_norm = (float)max_norm; a.tau = (float)tau; a.one_m_tau = (float)(1.0 - tau);
     a.part = part; a.gnorm_out = d_gnorm;
     MCTSQ_CHECK(tau < 0.0 || d_target, "target buffer is NULL but tau >= 0");
-    hipLaunchKernelGGL(clip_adam_polyak_kernel, dim3(stream_grid(n >> 2)), dim3(256), 0, st, a);
+    if (fused) hipLaunchKernelGGL(clip_adam_polyak_kernel<true>, dim3(stream_grid(n >> 2)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(clip_adam_polyak_kernel<false>, dim3(stream_grid(n >> 2)), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

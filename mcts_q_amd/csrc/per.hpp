@@ -27,19 +27,30 @@ struct PerGatherArgs {
 };
 
 typedef unsigned long long per_u64;
+// sample workspace: control words first (the normalisation ticket), raw fp64 weights behind them
+constexpr int64_t PER_WS_CTRL_BYTES = 64;
+// ga != NULL: the sampled records are gathered by the same launch (ga->phys is ignored)
 int launch_per_sample(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                       const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
-                      int64_t* phys, float* w, double* wmax, double* ws_w64, hipStream_t st);
+                      int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st);
 int launch_per_sample_at(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                          const per_u64* targets, int64_t B, double alpha, double beta, int64_t mass_cap,
                          double n_total, double mass_total, int64_t* idx, int64_t* phys, double* w64, double* wmax,
                          hipStream_t st);
+int launch_per_sample_shard(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
+                            const per_u64* targets, const int32_t* count, int64_t bcap, double alpha, double beta,
+                            int64_t mass_cap, const per_u64* shard_mass, const int64_t* shard_size, int world,
+                            int64_t* idx, int64_t* phys, double* w64, double* wmax, void* ws,
+                            const PerGatherArgs* ga, hipStream_t st);
+int launch_per_shard_select(const double* u, int64_t B, const per_u64* shard_mass, int world, int rank, int64_t bcap,
+                            per_u64* targets, int32_t* draw, int32_t* out, hipStream_t st);
 int launch_per_normalize(const double* w64, int64_t B, const double* wmax, float* w, hipStream_t st);
 int launch_per_shard_targets(const double* u, int64_t B, const per_u64* shard_mass, int world, int rank,
                              per_u64* targets, int32_t* mine, hipStream_t st);
-int launch_per_total_mass(const per_u64* tree, int64_t cap, per_u64* out, hipStream_t st);
-int launch_per_update(per_u64* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, const int64_t* idx,
-                      const float* newp, int64_t B, double alpha, int64_t mass_cap, hipStream_t st);
+int launch_per_total_mass(const per_u64* tree, int64_t cap, int64_t size, per_u64* out, hipStream_t st);
+int launch_per_update(per_u64* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, int64_t size,
+                      const int64_t* idx, const float* newp, int64_t B, double alpha, int64_t mass_cap,
+                      hipStream_t st);
 int launch_per_push(per_u64* tree, double* prio, const double* maxprio, int64_t cap, int64_t head,
                     int64_t size, int64_t K, double alpha, int64_t mass_cap, hipStream_t st);
 int launch_per_refresh_max(const double* prio, int64_t n_live, double* out, double* ws_part, int nparts_cap,

@@ -7,6 +7,10 @@
 #include "device_utils.hpp"
 #include "per.hpp"
 
+#include <string.h>
+
+#include <mutex>
+
 #pragma clang fp contract(off)
 
 namespace mctsq {
@@ -91,60 +95,224 @@ __device__ u64 prefix_mass(const u64* tree, const PerTree& T, int64_t n, int lan
 }
 
 // ------------------------------------------------------------------ sample
-__global__ __launch_bounds__(256) void per_sample_kernel(const u64* __restrict__ tree, PerTree T,
-                                                         const double* __restrict__ prio, int64_t cap,
-                                                         int64_t head, int64_t size,
-                                                         const double* __restrict__ u,
-                                                         const u64* __restrict__ targets, int64_t B,
-                                                         double alpha, double beta, int shift, double n_eff,
-                                                         double mass_eff,
-                                                         int64_t* __restrict__ idx_out,
-                                                         int64_t* __restrict__ phys_out,
-                                                         double* __restrict__ w64) {
-    const int lane = threadIdx.x & 63;
-    const int64_t draw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (draw >= B) return;                                   // wave-uniform
+// One workgroup = SMP_DRAWS draws, four per wave.  The two top levels of the tree (<= 64 + 4096 nodes) are staged
+// in LDS once per workgroup; below them every level costs one 512-byte node read per draw, and the four draws of a
+// wave have their reads in flight together.  A wave scans a node with a 64-wide integer prefix sum (shuffles).
+// Optional tails, all in the same launch:
+//   - gather (ga.phys == this kernel's phys_out): the wave that found a slot copies its 2 x 96-float record into
+//     the six window tensors (per_gather_kernel's job);
+//   - IS-weight normalisation (a.w != NULL): the workgroup whose ticket shows it is the last one to finish divides
+//     all B raw weights by their maximum.  Raw weights travel as write-through (sc1) stores and are read back
+//     with sc1 loads behind the ticket, so no cache maintenance is needed (MI355X_MICROARCH.md, hand-off table).
+constexpr int SMP_DRAWS = 16, SMP_PER_WAVE = 4, SMP_L2MAX = 4096;
+constexpr int64_t SMP_FUSED_NORM_MAX = 16384;      // beyond this many draws the normalisation is its own launch
+
+struct PerSampleArgs {
+    const u64* tree; PerTree T; const double* prio; int64_t cap, head, size;
+    const double* u;              // uniforms (single buffer) or NULL
+    const u64* targets;           // explicit integer targets (sharded) or NULL
+    const int32_t* count;         // device-side number of live draws (rows >= *count are padding) or NULL
+    int64_t B;
+    double alpha, beta; int shift;
+    double n_eff, mass_eff;       // totals of the whole (sharded) buffer when known on the host, else 0
+    const u64* shard_mass; const int64_t* shard_size; int world;   // ... or on the device
+    int64_t *idx_out, *phys_out; double* w64;
+    float* w; double* wmax; unsigned* ticket;     // fused normalisation (w may be NULL)
+    PerGatherArgs ga;             // fused gather when ga.states != NULL
+};
+
+__device__ __forceinline__ void gather_record(const PerGatherArgs& a, int64_t b, int64_t phys, int lane) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float* src = (which ? a.next_states : a.states) + phys * MCTSQ_STATE_ROW;
+        float* pp = which ? a.nprice : a.sprice; float* pc = which ? a.nprocess : a.sprocess; float* pg = which ? a.ngas : a.sgas;
+        const float v0 = src[lane];
+        const float v1 = lane < 27 ? src[64 + lane] : 0.0f;
+        if (lane < 25) pp[b * 25 + lane] = v0; else pc[b * 60 + (lane - 25)] = v0;
+        if (lane < 21) pc[b * 60 + 39 + lane] = v1; else if (lane < 27) pg[b * 6 + (lane - 21)] = v1;
+    }
+    if (lane == 0) { a.act[b] = a.actions[phys]; a.rew[b] = a.rewards[phys]; a.done[b] = a.dones[phys]; }
+}
+
+__global__ __launch_bounds__(256) void per_sample_kernel(PerSampleArgs a) {
+    __shared__ u64 s_l2[SMP_L2MAX];
+    __shared__ u64 s_head;
+    __shared__ double s_red[4];
+    __shared__ unsigned s_last;
+    const PerTree& T = a.T;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int top = T.nlev - 1;
-    u64 v = lane < T.cnt[top] ? tree[T.off[top] + lane] : 0;
-    u64 sc = wave_incl_scan(v, lane);
-    const u64 M = shfl_u64(sc, 63);
-    // u = k / 2^53 exactly (numpy random_sample); target t = floor(k * M / 2^53)
-    u64 t;
-    if (targets) {
-        t = targets[draw];                                   // sharded: local integer target
-    } else {
-        const u64 k = (u64)(u[draw] * 9007199254740992.0);
-        const u64 hi = __umul64hi(k, M), lo = k * M;
-        t = (hi << 11) | (lo >> 53);
+    const bool l2_staged = top >= 1 && T.cnt[top - 1] <= SMP_L2MAX;
+    if (l2_staged)
+        for (int i = tid; i < (int)T.cnt[top - 1]; i += 256) s_l2[i] = a.tree[T.off[top - 1] + i];
+    if (a.head != 0 && wv == 0) {                            // logical order starts at `head`
+        const u64 H = prefix_mass(a.tree, T, a.head, lane);
+        if (lane == 0) s_head = H;
     }
-    if (head != 0) {                                         // logical order starts at `head`
-        const u64 H = prefix_mass(tree, T, head, lane);
-        const u64 tail = M - H;
-        t = t < tail ? t + H : t - tail;
+    const int64_t nlive = a.count ? (int64_t)*a.count : a.B;
+    double n_eff = a.n_eff, mass_eff = a.mass_eff;
+    if (a.shard_mass) {                                      // totals of the concatenated shards, read on the device
+        u64 ms = 0; int64_t ns = 0;
+        for (int r = 0; r < a.world; ++r) { ms += a.shard_mass[r]; ns += a.shard_size[r]; }
+        n_eff = (double)ns; mass_eff = (double)ms;
     }
-    int64_t g = 0;
-    for (int l = top; l >= 0; --l) {
-        if (l != top) {
-            v = tree[T.off[l] + g * 64 + lane];
-            sc = wave_incl_scan(v, lane);
+    u64 v = lane < T.cnt[top] ? a.tree[T.off[top] + lane] : 0;
+    const u64 sc_top = wave_incl_scan(v, lane);
+    const u64 v_top = v;
+    const u64 M = shfl_u64(sc_top, 63);
+    __syncthreads();
+    const u64 H = a.head != 0 ? s_head : 0;
+
+    const int64_t d0 = (int64_t)blockIdx.x * SMP_DRAWS + wv * SMP_PER_WAVE;
+    u64 t[SMP_PER_WAVE];
+    int64_t g[SMP_PER_WAVE];
+    bool live[SMP_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < SMP_PER_WAVE; ++k) {
+        const int64_t d = d0 + k;
+        live[k] = d < a.B && d < nlive;                      // wave-uniform
+        u64 tt = 0;
+        if (live[k]) {
+            if (a.targets) {
+                tt = a.targets[d];                           // sharded: local integer target
+            } else {
+                // u = k / 2^53 exactly (numpy random_sample); target t = floor(k * M / 2^53)
+                const u64 kk = (u64)(a.u[d] * 9007199254740992.0);
+                const u64 hi = __umul64hi(kk, M), lo = kk * M;
+                tt = (hi << 11) | (lo >> 53);
+            }
+            if (a.head != 0) { const u64 tail = M - H; tt = tt < tail ? tt + H : tt - tail; }
         }
-        const unsigned long long ball = __ballot(sc > t);
-        int c = ball ? __ffsll((long long)ball) - 1 : 63;
-        const u64 excl = shfl_u64(sc - v, c);
-        t -= excl;
-        g = g * 64 + c;
+        const unsigned long long ball = __ballot(sc_top > tt);
+        const int c = ball ? __ffsll((long long)ball) - 1 : 63;
+        t[k] = tt - shfl_u64(sc_top - v_top, c);
+        g[k] = c;
     }
-    if (g >= cap) g = cap - 1;                               // unreachable for consistent trees
-    if (lane == 0) {
-        int64_t logical = g - head;
-        if (logical < 0) logical += cap;
-        idx_out[draw] = logical;
-        phys_out[draw] = g;
-        const double p = mctsq_pow_det(prio[g], alpha);
-        const double ratio = ((n_eff > 0.0 ? n_eff : (double)size) * p) * ldexp(1.0, shift) /
-                             (mass_eff > 0.0 ? mass_eff : (double)M);
-        w64[draw] = mctsq_pow_det(ratio, -beta);
+    for (int l = top - 1; l >= 0; --l) {
+        u64 vv[SMP_PER_WAVE];
+        const bool from_lds = l == top - 1 && l2_staged;
+#pragma unroll
+        for (int k = 0; k < SMP_PER_WAVE; ++k) {
+            const int64_t node = g[k] * 64 + lane;
+            vv[k] = node < T.cnt[l] ? (from_lds ? s_l2[node] : a.tree[T.off[l] + node]) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < SMP_PER_WAVE; ++k) {
+            const u64 sc = wave_incl_scan(vv[k], lane);
+            const unsigned long long ball = __ballot(sc > t[k]);
+            const int c = ball ? __ffsll((long long)ball) - 1 : 63;
+            t[k] -= shfl_u64(sc - vv[k], c);
+            g[k] = g[k] * 64 + c;
+        }
     }
+    // lane k finishes draw k: indices and the raw IS weight (N p_i / sum p)^-beta
+    double wraw = 0.0;
+    {
+        int64_t gm = 0; bool lv = false;
+#pragma unroll
+        for (int k = 0; k < SMP_PER_WAVE; ++k) if (lane == k) { gm = g[k]; lv = live[k]; }
+        if (gm >= a.cap) gm = a.cap - 1;                     // unreachable for consistent trees
+        const int64_t d = d0 + lane;
+        if (lane < SMP_PER_WAVE && d < a.B) {
+            if (lv) {
+                int64_t logical = gm - a.head;
+                if (logical < 0) logical += a.cap;
+                a.idx_out[d] = logical;
+                a.phys_out[d] = gm;
+                // the mass the sampler used (clamped like mctsq_mass), so weights and sampling law agree
+                const double p = fmin(mctsq_pow_det(a.prio[gm], a.alpha), 256.0);
+                const double ratio = ((n_eff > 0.0 ? n_eff : (double)a.size) * p) * ldexp(1.0, a.shift) /
+                                     (mass_eff > 0.0 ? mass_eff : (double)M);
+                wraw = mctsq_pow_det(ratio, -a.beta);
+            } else {                                         // padding row: neutral everywhere downstream
+                a.idx_out[d] = -1;
+                a.phys_out[d] = 0;
+            }
+            __hip_atomic_store(&a.w64[d], wraw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (a.ga.states) {
+#pragma unroll
+        for (int k = 0; k < SMP_PER_WAVE; ++k) {
+            const int64_t d = d0 + k;
+            if (d < a.B) gather_record(a.ga, d, live[k] ? (g[k] < a.cap ? g[k] : a.cap - 1) : 0, lane);
+        }
+    }
+    if (!a.w && !a.wmax) return;
+    // ---- workgroup maximum of the raw weights, then the ticket -------------------------------------------
+    double mx = wraw;
+    for (int dd = 2; dd >= 1; dd >>= 1) mx = fmax(mx, __shfl_xor(mx, dd, 64));
+    if (lane == 0) s_red[wv] = mx;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's sc1 stores have left before it signals
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    mx = 0.0;
+    for (int64_t i = tid; i < a.B; i += 256)
+        mx = fmax(mx, __hip_atomic_load(&a.w64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int dd = 32; dd >= 1; dd >>= 1) mx = fmax(mx, __shfl_xor(mx, dd, 64));
+    __syncthreads();
+    if (lane == 0) s_red[wv] = mx;
+    __syncthreads();
+    mx = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    if (a.w)
+        for (int64_t i = tid; i < a.B; i += 256)
+            a.w[i] = mx > 0.0 ? (float)(__hip_atomic_load(&a.w64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / mx) : 0.0f;
+    if (tid == 0) {
+        if (a.wmax) *a.wmax = mx;
+        *a.ticket = 0;                                       // ready for the next launch on this stream
+    }
+}
+
+// which of the B global draws fall into this rank's interval of the concatenated mass line, compacted to the
+// front of d_targets (draw order kept) with their positions; out[0] = count, out[1] = draws dropped because
+// they did not fit `bcap`.  One workgroup; t = floor(k * M / 2^53) exactly as the single-buffer form.
+__global__ __launch_bounds__(1024) void per_shard_select_kernel(const double* __restrict__ u, int64_t B,
+                                                                const u64* __restrict__ shard_mass, int world,
+                                                                int rank, int64_t bcap, u64* __restrict__ targets,
+                                                                int32_t* __restrict__ draw, int32_t* __restrict__ out) {
+    __shared__ int s_wsum[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    u64 M = 0, prefix = 0;
+    for (int r = 0; r < world; ++r) {
+        if (r < rank) prefix += shard_mass[r];
+        M += shard_mass[r];
+    }
+    const u64 own = shard_mass[rank];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < B; i0 += 1024) {
+        const int64_t i = i0 + tid;
+        bool m = false; u64 t = 0;
+        if (i < B) {
+            const u64 k = (u64)(u[i] * 9007199254740992.0);
+            const u64 hi = __umul64hi(k, M), lo = k * M;
+            t = (hi << 11) | (lo >> 53);
+            m = t >= prefix && t - prefix < own;
+        }
+        const unsigned long long ball = __ballot(m);
+        const int within = __popcll(ball & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wsum[wv] = __popcll(ball);
+        __syncthreads();
+        int before = s_base;
+        for (int w2 = 0; w2 < wv; ++w2) before += s_wsum[w2];
+        if (m) {
+            const int64_t pos = before + within;
+            if (pos < bcap) { targets[pos] = t - prefix; draw[pos] = (int32_t)i; }
+        }
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w2 = 0; w2 < 16; ++w2) tot += s_wsum[w2]; s_base += tot; }
+        __syncthreads();
+    }
+    const int total = s_base;
+    const int kept = total < bcap ? total : (int)bcap;
+    for (int64_t i = kept + tid; i < bcap; i += 1024) { targets[i] = 0; draw[i] = -1; }
+    if (tid == 0) { out[0] = kept; out[1] = total - kept; }
 }
 
 // global targets of a sharded buffer: shard `rank` owns [prefix, prefix + mass[rank]) of the
@@ -168,12 +336,12 @@ __global__ __launch_bounds__(256) void per_shard_targets_kernel(const double* __
     mine[i] = m ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void per_total_mass_kernel(const u64* __restrict__ tree, PerTree T,
+__global__ __launch_bounds__(64) void per_total_mass_kernel(const u64* __restrict__ tree, PerTree T, int64_t size,
                                                             u64* __restrict__ out) {
     const int lane = threadIdx.x, top = T.nlev - 1;
     u64 v = lane < T.cnt[top] ? tree[T.off[top] + lane] : 0;
     v = wave_incl_scan(v, lane);
-    if (lane == 63) *out = v;
+    if (lane == 63) { out[0] = v; out[1] = (u64)size; }
 }
 
 __global__ __launch_bounds__(1024) void per_weight_max_kernel(const double* __restrict__ w64, int64_t B,
@@ -228,14 +396,15 @@ __device__ __forceinline__ void set_leaf(u64* tree, const PerTree& T, int64_t ph
 // Sequential semantics (dqn_per.py:313-314): for duplicate indices the LAST occurrence wins.
 // Pass 1 records, per physical slot, the largest batch position that names it (atomicMax on an
 // int32 stamp array that is all -1 between calls); pass 2 lets exactly that position write and
-// resets the stamp.  O(B), any B.
+// resets the stamp.  O(B), any B.  Indices outside [0, size) name no stored transition and are skipped
+// (the reference raises IndexError for them; negative ones there address the deque from its end).
 __global__ __launch_bounds__(256) void per_update_mark_kernel(int32_t* __restrict__ stamp, int64_t cap,
-                                                              int64_t head, const int64_t* __restrict__ idx,
-                                                              int64_t B) {
+                                                              int64_t head, int64_t size,
+                                                              const int64_t* __restrict__ idx, int64_t B) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     const int64_t li = idx[i];
-    if (li < 0 || li >= cap) return;
+    if (li < 0 || li >= size) return;
     int64_t phys = head + li;
     if (phys >= cap) phys -= cap;
     atomicMax(&stamp[phys], (int32_t)i);
@@ -243,14 +412,14 @@ __global__ __launch_bounds__(256) void per_update_mark_kernel(int32_t* __restric
 
 __global__ __launch_bounds__(256) void per_update_kernel(u64* __restrict__ tree, PerTree T,
                                                          double* __restrict__ prio, int32_t* __restrict__ stamp,
-                                                         int64_t cap, int64_t head,
+                                                         int64_t cap, int64_t head, int64_t size,
                                                          const int64_t* __restrict__ idx,
                                                          const float* __restrict__ newp, int64_t B,
                                                          double alpha, int shift) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     const int64_t li = idx[i];
-    if (li < 0 || li >= cap) return;
+    if (li < 0 || li >= size) return;
     int64_t phys = head + li;
     if (phys >= cap) phys -= cap;
     if (stamp[phys] != (int32_t)i) return;
@@ -258,6 +427,62 @@ __global__ __launch_bounds__(256) void per_update_kernel(u64* __restrict__ tree,
     const double p = (double)newp[i];
     prio[phys] = p;
     set_leaf(tree, T, phys, mctsq_mass(p, alpha, shift));
+}
+
+// Both passes in ONE workgroup for batches up to UPD_FUSED_MAX (the training batch): the marks of all positions are
+// made before any position writes because a workgroup barrier separates them, and the mass deltas of the two top
+// levels (<= 64 + 4096 nodes, where every update of the batch collides) are first summed in LDS, so each of those
+// nodes receives one global add per launch instead of one per update.
+constexpr int UPD_FUSED_MAX = 4096;
+__global__ __launch_bounds__(1024) void per_update_fused_kernel(u64* __restrict__ tree, PerTree T,
+                                                                double* __restrict__ prio,
+                                                                int32_t* __restrict__ stamp, int64_t cap,
+                                                                int64_t head, int64_t size,
+                                                                const int64_t* __restrict__ idx,
+                                                                const float* __restrict__ newp, int64_t B,
+                                                                double alpha, int shift) {
+    __shared__ u64 s_top[64], s_l2[SMP_L2MAX];
+    const int tid = threadIdx.x, top = T.nlev - 1;
+    const bool lds_top = top >= 1, lds_l2 = top >= 2 && T.cnt[top - 1] <= SMP_L2MAX;
+    if (tid < 64) s_top[tid] = 0;
+    if (lds_l2) for (int i = tid; i < (int)T.cnt[top - 1]; i += 1024) s_l2[i] = 0;
+    for (int64_t i = tid; i < B; i += 1024) {
+        const int64_t li = idx[i];
+        if (li < 0 || li >= size) continue;
+        int64_t phys = head + li;
+        if (phys >= cap) phys -= cap;
+        atomicMax(&stamp[phys], (int32_t)i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                         // every mark of the batch has been performed
+    for (int64_t i = tid; i < B; i += 1024) {
+        const int64_t li = idx[i];
+        if (li < 0 || li >= size) continue;
+        int64_t phys = head + li;
+        if (phys >= cap) phys -= cap;
+        // read the final mark where the atomics executed: repeating this position's own max returns it unchanged
+        if (atomicMax(&stamp[phys], (int32_t)i) != (int32_t)i) continue;
+        stamp[phys] = -1;
+        const double p = (double)newp[i];
+        prio[phys] = p;
+        const u64 m = mctsq_mass(p, alpha, shift);
+        const u64 old = tree[T.off[0] + phys];
+        tree[T.off[0] + phys] = m;
+        const u64 delta = m - old;                           // wraps for decreases; sums stay exact
+        if (delta == 0) continue;
+        int64_t node = phys;
+        for (int l = 1; l <= top; ++l) {
+            node >>= 6;
+            if (l == top && lds_top) atomicAdd(&s_top[node], delta);
+            else if (l == top - 1 && lds_l2) atomicAdd(&s_l2[node], delta);
+            else atomicAdd(&tree[T.off[l] + node], delta);
+        }
+    }
+    __syncthreads();
+    if (lds_top && tid < (int)T.cnt[top] && s_top[tid] != 0) atomicAdd(&tree[T.off[top] + tid], s_top[tid]);
+    if (lds_l2)
+        for (int i = tid; i < (int)T.cnt[top - 1]; i += 1024)
+            if (s_l2[i] != 0) atomicAdd(&tree[T.off[top - 1] + i], s_l2[i]);
 }
 
 __global__ __launch_bounds__(256) void per_push_kernel(u64* __restrict__ tree, PerTree T,
@@ -347,29 +572,67 @@ int per_mass_shift(int64_t cap) {
     return s > 44 ? 44 : s;
 }
 
-int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
-                      const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
-                      int64_t* phys, float* w, double* wmax, double* ws_w64, hipStream_t st) {
-    PerTree T;
-    if (per_tree_desc(cap, &T)) return -1;
-    const int shift = per_mass_shift(mass_cap);
-    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, tree, T, prio, cap,
-                       head, size, u, (const u64*)nullptr, B, alpha, beta, shift, 0.0, 0.0, idx, phys, ws_w64);
-    hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, ws_w64, B, w, wmax);
+static int sample_launch(PerSampleArgs& a, void* ws, hipStream_t st) {
+    // workspace: [0, 64) control words (the ticket: zero when first handed over, left zero by every launch),
+    // raw fp64 weights behind them unless the caller supplies its own array
+    a.ticket = reinterpret_cast<unsigned*>(ws);
+    const bool fused_norm = (a.w || a.wmax) && a.B <= SMP_FUSED_NORM_MAX && ws != nullptr;
+    float* w = a.w; double* wmax = a.wmax;
+    if (!fused_norm) { a.w = nullptr; a.wmax = nullptr; }
+    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((a.B + SMP_DRAWS - 1) / SMP_DRAWS)), dim3(256), 0, st, a);
+    if (!fused_norm && w) hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, w, wmax);
+    else if (!fused_norm && wmax) hipLaunchKernelGGL(per_weight_max_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, wmax);
     MCTSQ_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
+                      const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
+                      int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st) {
+    PerSampleArgs a;
+    memset(&a, 0, sizeof(a));
+    if (per_tree_desc(cap, &a.T)) return -1;
+    a.tree = tree; a.prio = prio; a.cap = cap; a.head = head; a.size = size; a.u = u; a.B = B;
+    a.alpha = alpha; a.beta = beta; a.shift = per_mass_shift(mass_cap);
+    a.idx_out = idx; a.phys_out = phys; a.w64 = reinterpret_cast<double*>((char*)ws + PER_WS_CTRL_BYTES);
+    a.w = w; a.wmax = wmax;
+    if (ga) a.ga = *ga;
+    return sample_launch(a, ws, st);
 }
 
 int launch_per_sample_at(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                          const u64* targets, int64_t B, double alpha, double beta, int64_t mass_cap, double n_total,
                          double mass_total, int64_t* idx, int64_t* phys, double* w64, double* wmax,
                          hipStream_t st) {
-    PerTree T;
-    if (per_tree_desc(cap, &T)) return -1;
-    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, tree, T, prio, cap,
-                       head, size, (const double*)nullptr, targets, B, alpha, beta, per_mass_shift(mass_cap),
-                       n_total, mass_total, idx, phys, w64);
-    if (wmax) hipLaunchKernelGGL(per_weight_max_kernel, dim3(1), dim3(1024), 0, st, w64, B, wmax);
+    PerSampleArgs a;
+    memset(&a, 0, sizeof(a));
+    if (per_tree_desc(cap, &a.T)) return -1;
+    a.tree = tree; a.prio = prio; a.cap = cap; a.head = head; a.size = size; a.targets = targets; a.B = B;
+    a.alpha = alpha; a.beta = beta; a.shift = per_mass_shift(mass_cap); a.n_eff = n_total; a.mass_eff = mass_total;
+    a.idx_out = idx; a.phys_out = phys; a.w64 = w64; a.wmax = wmax;
+    return sample_launch(a, nullptr, st);                    // no control words here: the maximum is its own launch
+}
+
+int launch_per_sample_shard(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
+                            const u64* targets, const int32_t* count, int64_t bcap, double alpha, double beta,
+                            int64_t mass_cap, const u64* shard_mass, const int64_t* shard_size, int world,
+                            int64_t* idx, int64_t* phys, double* w64, double* wmax, void* ws,
+                            const PerGatherArgs* ga, hipStream_t st) {
+    PerSampleArgs a;
+    memset(&a, 0, sizeof(a));
+    if (per_tree_desc(cap, &a.T)) return -1;
+    a.tree = tree; a.prio = prio; a.cap = cap; a.head = head; a.size = size; a.targets = targets; a.count = count;
+    a.B = bcap; a.alpha = alpha; a.beta = beta; a.shift = per_mass_shift(mass_cap);
+    a.shard_mass = shard_mass; a.shard_size = shard_size; a.world = world;
+    a.idx_out = idx; a.phys_out = phys; a.w64 = w64; a.wmax = wmax;
+    if (ga) a.ga = *ga;
+    return sample_launch(a, ws, st);
+}
+
+int launch_per_shard_select(const double* u, int64_t B, const u64* shard_mass, int world, int rank, int64_t bcap,
+                            u64* targets, int32_t* draw, int32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(per_shard_select_kernel, dim3(1), dim3(1024), 0, st, u, B, shard_mass, world, rank, bcap,
+                       targets, draw, out);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
@@ -388,22 +651,29 @@ int launch_per_shard_targets(const double* u, int64_t B, const u64* shard_mass, 
     return 0;
 }
 
-int launch_per_total_mass(const u64* tree, int64_t cap, u64* out, hipStream_t st) {
+int launch_per_total_mass(const u64* tree, int64_t cap, int64_t size, u64* out, hipStream_t st) {
     PerTree T;
     if (per_tree_desc(cap, &T)) return -1;
-    hipLaunchKernelGGL(per_total_mass_kernel, dim3(1), dim3(64), 0, st, tree, T, out);
+    hipLaunchKernelGGL(per_total_mass_kernel, dim3(1), dim3(64), 0, st, tree, T, size, out);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_per_update(u64* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, const int64_t* idx,
-                      const float* newp, int64_t B, double alpha, int64_t mass_cap, hipStream_t st) {
+int launch_per_update(u64* tree, double* prio, int32_t* stamp, int64_t cap, int64_t head, int64_t size,
+                      const int64_t* idx, const float* newp, int64_t B, double alpha, int64_t mass_cap,
+                      hipStream_t st) {
     PerTree T;
     if (per_tree_desc(cap, &T)) return -1;
-    const dim3 grid((unsigned)((B + 255) / 256));
-    hipLaunchKernelGGL(per_update_mark_kernel, grid, dim3(256), 0, st, stamp, cap, head, idx, B);
-    hipLaunchKernelGGL(per_update_kernel, grid, dim3(256), 0, st, tree, T, prio, stamp, cap, head, idx, newp, B,
-                       alpha, per_mass_shift(mass_cap));
+    const int shift = per_mass_shift(mass_cap);
+    if (B <= UPD_FUSED_MAX) {
+        hipLaunchKernelGGL(per_update_fused_kernel, dim3(1), dim3(1024), 0, st, tree, T, prio, stamp, cap, head, size,
+                           idx, newp, B, alpha, shift);
+    } else {
+        const dim3 grid((unsigned)((B + 255) / 256));
+        hipLaunchKernelGGL(per_update_mark_kernel, grid, dim3(256), 0, st, stamp, cap, head, size, idx, B);
+        hipLaunchKernelGGL(per_update_kernel, grid, dim3(256), 0, st, tree, T, prio, stamp, cap, head, size, idx, newp,
+                           B, alpha, shift);
+    }
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -119,6 +119,7 @@ class TripleEncoderDQN:
                             hidden_units=int(hidden_units), action_dim=int(action_dim), seq=tuple(seq_lens),
                             data_dim=(el_input_dim - extra, process_input_dim - extra, gas_eua_input_dim - extra))
         self._dims = (el_input_dim, process_input_dim, gas_eua_input_dim, int(embed_dim))
+        self._check_replay_geometry()
         self.qnet = _qnet if _qnet is not None else DeviceQNet(self.spec, device)
         self.device = self.qnet.device
         if _qnet is None:
@@ -126,6 +127,15 @@ class TripleEncoderDQN:
                 el_input_dim, process_input_dim, gas_eua_input_dim, int(embed_dim), int(hidden_layers),
                 int(hidden_units), int(action_dim), price_encoder_type, process_encoder_type, gas_eua_encoder_type))
         self.training = True
+
+    def _check_replay_geometry(self, training: bool = False):
+        """The replay ring stores 91-scalar records: price 25 | process 10 x 6 | gas/EUA 3 x 2
+        (include/mctsq_hip.h: MCTSQ_STATE_ROW, mctsq_per_gather).  The network itself accepts other window
+        lengths for leaf evaluation; DQNModel (which trains from the ring) does not."""
+        if training and (tuple(self.spec.seq) != (25, 10, 3) or tuple(self.spec.data_dim) != (1, 6, 2)):
+            raise MctsqError(f"the device replay stores windows of 25x1 / 10x6 / 3x2 (config_env.yaml:30-33, "
+                             f"config_mctsq.yaml:32); got seq_lens {tuple(self.spec.seq)}, data dims "
+                             f"{tuple(self.spec.data_dim)}")
 
     # nn.Module look-alikes used by the reference's callers
     def eval(self):
@@ -181,8 +191,12 @@ class PrioritizedReplayBuffer:
 
     # ---- reference API ---------------------------------------------------------------------
     def push(self, state, action, reward, next_state, done) -> None:
-        self._pend_rows.append(obs_to_row(state))
-        self._pend_next.append(obs_to_row(next_state))
+        row, nrow = obs_to_row(state), obs_to_row(next_state)
+        if row.size != 91 or nrow.size != 91:          # ring records are price 25 | process 10 x 6 | gas 3 x 2
+            raise MctsqError(f"observation has {row.size} scalars; the device replay stores 91-scalar states "
+                             "(25 price + 10 x 6 process + 3 x 2 gas/EUA steps)")
+        self._pend_rows.append(row)
+        self._pend_next.append(nrow)
         self._pend_a.append(int(action)); self._pend_r.append(float(reward)); self._pend_d.append(float(done))
         if len(self._pend_rows) >= min(self._flush_every, self.capacity):
             self.flush()
@@ -203,8 +217,8 @@ class PrioritizedReplayBuffer:
         Uniforms come from the global numpy RNG, the stream np.random.choice draws from (:292)."""
         self.flush()
         u = np.random.random_sample(int(batch_size))
-        idx, phys, w = self.dev.sample_indices(u, beta=beta)
-        return self.dev.gather(phys), w, idx
+        batch, w, idx, _ = self.dev.sample_batch(u, beta=beta)     # sample + IS weights + gather: one launch
+        return batch, w, idx
 
     def sample(self, batch_size: int, beta: float = 0.4):
         """Reference-shaped result (:303-305): (states, actions, rewards, next_states, dones, weights,
@@ -310,6 +324,7 @@ class DQNModel:
         args = (el_input_dim, process_input_dim, gas_eua_input_dim, embed_dim, hidden_layers, hidden_units,
                 action_dim, price_encoder_type, process_encoder_type, gas_eua_encoder_type, activation)
         self.policy_net = self._net_cls(*args, device=device, seq_lens=seq_lens)
+        self.policy_net._check_replay_geometry(training=True)
         self.learner = DeviceLearner(self.policy_net.spec, device, gamma=gamma, lr=lr, process_group=process_group,
                                      policy=self.policy_net.qnet)
         # the reference constructs (and default-initialises) the target net before overwriting it

@@ -28,15 +28,18 @@ class DeviceLearner:
         z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
         self.policy = policy if policy is not None else DeviceQNet(spec, self.device)
         self.target = DeviceQNet(spec, self.device)
-        self.grad, self.exp_avg, self.exp_avg_sq = z(), z(), z()
+        # flat gradient with the loss in the word behind it: data-parallel runs all-reduce both in ONE call
+        self._gradbuf = torch.zeros(n + 16, dtype=torch.float32, device=self.device)
+        self.grad, self.loss = self._gradbuf[:n], self._gradbuf[n:n + 1]
+        self.exp_avg, self.exp_avg_sq = z(), z()
         self.gamma, self.lr, self.betas, self.eps = float(gamma), float(lr), betas, float(eps)
         self.max_grad_norm = float(max_grad_norm)
         self.step_count = 0
         self.group = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self._ws = None
-        self._small = torch.zeros(4096, dtype=torch.uint8, device=self.device)     # norm partials
-        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._small = torch.zeros(int(lib.mctsq_optim_workspace_bytes()), dtype=torch.uint8,
+                                  device=self.device)                             # grad-norm partials
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def _st(self):
@@ -48,24 +51,41 @@ class DeviceLearner:
         return self
 
     # ---- gradient of the IS-weighted TD loss (dqn_per.py:455-470) ------------------------------
-    def compute_grad(self, batch: dict, isw: torch.Tensor, global_batch: int | None = None):
-        """batch: dict from DevicePER.gather (sprice.. ngas, act, rew, done) on this device; isw fp32 [B].
-        Fills self.grad (unclipped; after the all-reduce when data-parallel) and self.loss (local mean);
-        returns |td| fp32 [B] (the new priorities).  `global_batch` = draws over all ranks (default
-        B * world); B may be 0 on a rank that received no draw."""
+    def _check_batch(self, batch, isw):
         B = int(isw.numel())
+        for key, i in (("sprice", 0), ("sprocess", 1), ("sgas", 2), ("nprice", 0), ("nprocess", 1), ("ngas", 2)):
+            want = (B, self.spec.seq[i], self.spec.data_dim[i])
+            t = batch[key]
+            if tuple(t.shape) != want or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"batch[{key!r}]: expected contiguous fp32 {want} on {self.device}, got "
+                                 f"{tuple(t.shape)} {t.dtype} on {t.device}")
+        for key, dt in (("act", torch.int32), ("rew", torch.float32), ("done", torch.float32)):
+            t = batch[key]
+            if tuple(t.shape) != (B,) or t.dtype != dt or t.device != self.device:
+                raise ValueError(f"batch[{key!r}]: expected {dt} [{B}] on {self.device}")
+        if isw.dtype != torch.float32 or isw.device != self.device:
+            raise ValueError("importance weights must be fp32 on the learner's device")
+        return B
+
+    def compute_grad(self, batch: dict, isw: torch.Tensor, global_batch: int | None = None):
+        """batch: dict from DevicePER.gather / sample_batch (sprice.. ngas, act, rew, done) on this device; isw
+        fp32 [B] (rows with weight 0 are padding and contribute nothing).  Fills self.grad (unclipped) and self.loss
+        with the GLOBAL-batch mean (after one all-reduce over both when data-parallel); returns |td| fp32 [B] (the
+        new priorities).  `global_batch` = draws over all ranks (default B * world); B may be 0 on a rank that
+        received no draw."""
+        B = self._check_batch(batch, isw)
         if global_batch is None:
             global_batch = B * self.world
         if B == 0:
-            self.grad.zero_(); self.loss.zero_()
+            self._gradbuf.zero_()
             if self.world > 1:
-                all_reduce(self.grad, group=self.group)
-                all_reduce(self.loss, group=self.group)
+                all_reduce(self._gradbuf, group=self.group)
             return torch.empty(0, dtype=torch.float32, device=self.device)
         need = lib.check(lib.mctsq_dqn_grad_workspace_bytes(C.byref(self.desc), B))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         abs_td = torch.empty(B, dtype=torch.float32, device=self.device)
+        # loss_scale = B_local / B_global: gradient and loss of this rank's rows as their share of the global mean
         lib.check(lib.mctsq_dqn_grad(
             C.byref(self.desc), ptr(self.policy.flat), ptr(self.target.flat),
             ptr(batch["sprice"]), ptr(batch["sprocess"]), ptr(batch["sgas"]),
@@ -73,10 +93,8 @@ class DeviceLearner:
             ptr(batch["act"]), ptr(batch["rew"]), ptr(batch["done"]), ptr(isw),
             self.gamma, B / float(global_batch), B, ptr(self.grad), ptr(self.loss), ptr(abs_td), None, None,
             ptr(self._ws), self._ws.numel(), self._st()))
-        if self.world > 1:                      # data-parallel: one flat-gradient all-reduce (RCCL)
-            all_reduce(self.grad, group=self.group)
-            self.loss.mul_(B / float(global_batch))           # global mean = sum_r (B_r / B) * local mean
-            all_reduce(self.loss, group=self.group)
+        if self.world > 1:                      # data-parallel: ONE all-reduce (RCCL) over [gradient | loss]
+            all_reduce(self._gradbuf, group=self.group)
         return abs_td
 
     # ---- clip_grad_norm_(10) + Adam.step (+ Polyak) (dqn_per.py:471-472, 510-516) ---------------

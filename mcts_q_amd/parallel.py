@@ -7,13 +7,21 @@
   the W root masses are all-gathered, and each rank serves the draws that land in its interval of
   the concatenated mass line.  IS weights use the global N, the global mass and the global maximum.
 * Update: each rank back-propagates its own draws with the loss scaled by B_local / B_global, ONE
-  all-reduce(SUM) over the flat gradient buffer yields the exact global-batch gradient, then every
-  rank applies the identical clip / Adam / Polyak step, so replicas stay bit-identical.
+  all-reduce(SUM) over the flat gradient buffer (+ the loss behind it) yields the exact global-batch
+  gradient, then every rank applies the identical clip / Adam / Polyak step, so replicas stay bit-identical.
 
-The functions take a `shard` object (DevicePER, or any stand-in with the same five methods) and a
-process group, so the host logic is exercised on CPU with the gloo backend (tests/test_parallel_cpu.py).
+Nothing here reads device memory on the host inside a step.  The number of draws a rank serves varies from
+step to step, so every rank provisions a fixed number of rows (`draw_capacity`) and the kernels pad the
+unused ones with weight 0 / index -1: such rows contribute exactly nothing to loss, gradient and priorities.
+The (kept, dropped) counters of a step are copied to pinned host memory asynchronously and looked at one
+step later; a dropped draw (the rank's share outgrew its provision) raises.
+
+The functions take a `shard` object (DevicePER, or any stand-in with the same methods) and a process group,
+so the host logic is exercised on CPU with the gloo backend (tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
+
+import math
 
 import torch
 import torch.distributed as dist
@@ -36,34 +44,88 @@ def all_reduce(t: torch.Tensor, op=None, group=None):
     return t
 
 
+def all_gather_rows(local: torch.Tensor, group=None):
+    """[k] on every rank -> [W, k] on the device (host-staged under gloo like all_reduce)."""
+    world, _ = _world(group)
+    if world == 1:
+        return local.unsqueeze(0)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        c = local.cpu()
+        parts = [torch.empty_like(c) for _ in range(world)]
+        dist.all_gather(parts, c, group=group)
+        return torch.stack(parts).to(local.device)
+    out = torch.empty(world, local.numel(), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local.contiguous(), group=group)
+    return out
+
+
 def shared_uniforms(rng, batch_size: int):
     """The B global draws.  `rng` is a numpy RandomState / Generator seeded identically on every rank."""
     return rng.random_sample(int(batch_size))
 
 
-def sharded_sample(shard, u, group=None, beta: float = 0.4):
-    """Sample the concatenation of all ranks' shards at the global uniforms `u` (fp64 [B], identical
-    on every rank).  Returns dict(idx, phys: local indices of THIS rank's draws, w: their fp32 IS
-    weights, draw: positions of those draws in `u`, n_global, batch_global)."""
-    world, rank = _world(group)
-    dev = shard.device
-    local = torch.stack([shard.total_mass().reshape(()), torch.tensor(len(shard), dtype=torch.int64, device=dev)])
-    if world > 1:
-        allv = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(allv, local, group=group)
-        allv = torch.stack(allv)                               # [W, 2] on the device, no host sync
-    else:
-        allv = local.unsqueeze(0)
-    masses, sizes = allv[:, 0].contiguous(), allv[:, 1]
-    targets, mine = shard.shard_targets(u, masses, rank)
-    draw = torch.nonzero(mine, as_tuple=False).squeeze(1)      # the one host sync: B_local is a launch size
-    n_total = float(sizes.sum().item())
-    mass_total = float(sum(int(m) for m in masses.tolist()))
-    idx, phys, w64, wmax = shard.sample_at(targets[draw], n_total, mass_total, beta=beta)
-    if world > 1:
-        all_reduce(wmax, dist.ReduceOp.MAX, group)
-    w = shard.normalize_weights(w64, wmax)
-    return dict(idx=idx, phys=phys, w=w, draw=draw, n_global=int(n_total), batch_global=int(u.shape[0]))
+def draw_capacity(batch_global: int, world: int, share: float | None = None, sigmas: float = 10.0) -> int:
+    """Rows a rank provisions for its share of B global draws: mean + `sigmas` standard deviations of
+    Binomial(B, share) + 16, rounded up to the kernels' 16-row tile, never more than B rounded up."""
+    B = int(batch_global)
+    if world <= 1:
+        return B
+    p = 1.0 / world if share is None else min(1.0, max(0.0, float(share)))
+    n = B * p + sigmas * math.sqrt(max(B * p * (1.0 - p), 1.0)) + 16
+    return int(min(-(-B // 16) * 16, -(-int(math.ceil(n)) // 16) * 16))
+
+
+class ShardedSampler:
+    """Per-rank state of the sync-free sharded sampling: the row provision and the lagged look at the
+    previous step's counters."""
+
+    def __init__(self, shard, group=None, beta: float = 0.4, bcap: int | None = None):
+        self.shard, self.group, self.beta, self.bcap = shard, group, float(beta), bcap
+        self.world, self.rank = _world(group)
+        self._pending = None            # (pinned host copy of [kept, dropped], event) of the previous step
+
+    def _check_previous(self):
+        if self._pending is None:
+            return
+        host, ev = self._pending
+        if ev is not None:
+            ev.synchronize()            # recorded a whole step ago: already complete, no stall
+        if int(host[1]) != 0:
+            raise RuntimeError(f"sharded replay: {int(host[1])} draws of the previous step exceeded this rank's "
+                               f"provision of {self.bcap} rows; raise bcap (draw_capacity)")
+        self._pending = None
+
+    def sample(self, u):
+        """u: fp64 [B] global uniforms, identical on every rank.  Returns dict(batch, idx (-1 = padding), w fp32
+        (0 = padding), draw int32 positions in u (-1 = padding), count int32 [2] device, batch_global)."""
+        shard, group = self.shard, self.group
+        dev = shard.device
+        self._check_previous()
+        u = torch.as_tensor(u, dtype=torch.float64).to(dev)
+        B = int(u.numel())
+        if self.bcap is None:
+            self.bcap = draw_capacity(B, self.world)
+        allv = all_gather_rows(shard.mass_and_size(), group)      # [W, 2] on the device
+        masses, sizes = allv[:, 0].contiguous(), allv[:, 1].contiguous()
+        targets, draw, count = shard.shard_select(u, masses, self.rank, self.bcap)
+        batch, idx, w64, wmax = shard.sample_shard(targets, count, masses, sizes, beta=self.beta)
+        if self.world > 1:
+            all_reduce(wmax, dist.ReduceOp.MAX, group)
+        w = shard.normalize_weights(w64, wmax)
+        if count.is_cuda:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._pending = (host, ev)
+        else:
+            self._pending = (count.clone(), None)
+        return dict(batch=batch, idx=idx, w=w, draw=draw, count=count, batch_global=B)
+
+
+def sharded_sample(shard, u, group=None, beta: float = 0.4, bcap: int | None = None):
+    """One-shot form of ShardedSampler.sample (tests, single calls)."""
+    return ShardedSampler(shard, group, beta, bcap).sample(u)
 
 
 def allreduce_gradient(flat_grad: torch.Tensor, group=None):

@@ -38,7 +38,7 @@ class DevicePER:
         self.dones = torch.zeros(self.capacity, dtype=torch.float32, device=d)
         self.stamp = torch.full((self.capacity,), -1, dtype=torch.int32, device=d)
         self._max_dirty = False
-        self._ws = torch.empty(1 << 16, dtype=torch.uint8, device=d)
+        self._ws = torch.zeros(1 << 16, dtype=torch.uint8, device=d)      # control words must start out zero
         self.last_local_wmax = torch.ones(1, dtype=torch.float64, device=d)   # max IS weight before normalisation
 
     def __len__(self):
@@ -50,7 +50,7 @@ class DevicePER:
     def _ws_for(self, B):
         need = lib.check(lib.mctsq_per_workspace_bytes(self.capacity, B))
         if self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = torch.zeros(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
     # ---- push -------------------------------------------------------------------------
@@ -116,12 +116,49 @@ class DevicePER:
                                        ptr(self.last_local_wmax), ptr(ws), ws.numel(), self._st()))
         return idx, phys, w
 
+    def _batch_tensors(self, B):
+        d = self.device
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=d)
+        return dict(sprice=f(B, 25, 1), sprocess=f(B, 10, 6), sgas=f(B, 3, 2), nprice=f(B, 25, 1),
+                    nprocess=f(B, 10, 6), ngas=f(B, 3, 2), act=torch.empty(B, dtype=torch.int32, device=d),
+                    rew=f(B), done=f(B))
+
+    def _ring_ptrs(self):
+        return (ptr(self.states), ptr(self.next_states), ptr(self.actions), ptr(self.rewards), ptr(self.dones))
+
+    @staticmethod
+    def _batch_ptrs(out):
+        return tuple(ptr(out[k]) for k in ("sprice", "sprocess", "sgas", "nprice", "nprocess", "ngas", "act", "rew",
+                                           "done"))
+
+    def sample_batch(self, u, beta: float = 0.4):
+        """sample_indices + gather in ONE launch (dqn_per.py:283-305, 415-452): returns (batch dict of device
+        tensors, IS weights fp32 [B], logical idx int64 [B], physical slots int64 [B])."""
+        if self.size == 0:
+            raise ValueError("cannot sample from an empty buffer")
+        u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
+        B = u.numel()
+        idx = torch.empty(B, dtype=torch.int64, device=self.device)
+        phys = torch.empty(B, dtype=torch.int64, device=self.device)
+        w = torch.empty(B, dtype=torch.float32, device=self.device)
+        out = self._batch_tensors(B)
+        ws = self._ws_for(B)
+        lib.check(lib.mctsq_per_sample_batch(ptr(self.tree), ptr(self.prio), self.capacity, self.head, self.size,
+                                             ptr(u), B, self.alpha, beta, self.mass_capacity, ptr(idx), ptr(phys),
+                                             ptr(w), ptr(self.last_local_wmax), *self._ring_ptrs(),
+                                             *self._batch_ptrs(out), ptr(ws), ws.numel(), self._st()))
+        return out, w, idx, phys
+
     # ---- shard primitives (one ring = one shard of a buffer sampled as a whole; parallel.py) ------
-    def total_mass(self):
-        """Root of the sum-tree as an int64 device tensor [1] (uint64 bit pattern, < 2^62)."""
-        out = torch.zeros(1, dtype=torch.int64, device=self.device)
-        lib.check(lib.mctsq_per_total_mass(ptr(self.tree), self.capacity, ptr(out), self._st()))
+    def mass_and_size(self):
+        """int64 device tensor [2] = (root of the sum-tree as a uint64 bit pattern < 2^62, live entries): the pair
+        the ranks all-gather; made on the device so no host value is copied in."""
+        out = torch.empty(2, dtype=torch.int64, device=self.device)
+        lib.check(lib.mctsq_per_total_mass(ptr(self.tree), self.capacity, self.size, ptr(out), self._st()))
         return out
+
+    def total_mass(self):
+        return self.mass_and_size()[:1]
 
     def shard_targets(self, u, shard_mass, rank: int):
         """u fp64 [B] (the SAME draws on every rank), shard_mass int64 [W] -> (local integer targets
@@ -134,6 +171,34 @@ class DevicePER:
         lib.check(lib.mctsq_per_shard_targets(ptr(u), B, ptr(shard_mass), shard_mass.numel(), int(rank),
                                               ptr(targets), ptr(mine), self._st()))
         return targets, mine
+
+    def shard_select(self, u, shard_mass, rank: int, bcap: int):
+        """This rank's share of the global draws `u`, compacted on the device: (targets int64 [bcap], draw
+        positions int32 [bcap] (-1 = padding), count int32 [2] = (kept, dropped))."""
+        u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
+        targets = torch.empty(bcap, dtype=torch.int64, device=self.device)
+        draw = torch.empty(bcap, dtype=torch.int32, device=self.device)
+        count = torch.empty(2, dtype=torch.int32, device=self.device)
+        lib.check(lib.mctsq_per_shard_select(ptr(u), u.numel(), ptr(shard_mass), shard_mass.numel(), int(rank),
+                                             int(bcap), ptr(targets), ptr(draw), ptr(count), self._st()))
+        return targets, draw, count
+
+    def sample_shard(self, targets, count, shard_mass, shard_size, beta: float = 0.4):
+        """bcap rows at the compacted targets, totals from the all-gathered device arrays, transitions gathered
+        in the same launch: (batch, logical idx (-1 = padding), raw fp64 weights, local max fp64 [1])."""
+        bcap = targets.numel()
+        idx = torch.empty(bcap, dtype=torch.int64, device=self.device)
+        phys = torch.empty(bcap, dtype=torch.int64, device=self.device)
+        w64 = torch.empty(bcap, dtype=torch.float64, device=self.device)
+        wmax = torch.empty(1, dtype=torch.float64, device=self.device)
+        out = self._batch_tensors(bcap)
+        ws = self._ws_for(1)
+        lib.check(lib.mctsq_per_sample_shard(ptr(self.tree), ptr(self.prio), self.capacity, self.head, self.size,
+                                             ptr(targets), ptr(count), bcap, self.alpha, beta, self.mass_capacity,
+                                             ptr(shard_mass), ptr(shard_size), shard_mass.numel(), ptr(idx),
+                                             ptr(phys), ptr(w64), ptr(wmax), *self._ring_ptrs(),
+                                             *self._batch_ptrs(out), ptr(ws), ws.numel(), self._st()))
+        return out, idx, w64, wmax
 
     def sample_at(self, targets, n_total: float, mass_total: float, beta: float = 0.4):
         """Local draws at explicit integer targets -> (logical idx, physical slot, raw fp64 weights,
@@ -158,21 +223,19 @@ class DevicePER:
 
     def gather(self, phys):
         """Batch assembly (dqn_per.py:415-452) on the device: six window tensors + a, r, done."""
-        B, d = phys.numel(), self.device
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=d)
-        out = dict(sprice=f(B, 25, 1), sprocess=f(B, 10, 6), sgas=f(B, 3, 2), nprice=f(B, 25, 1),
-                   nprocess=f(B, 10, 6), ngas=f(B, 3, 2), act=torch.empty(B, dtype=torch.int32, device=d),
-                   rew=f(B), done=f(B))
-        lib.check(lib.mctsq_per_gather(ptr(self.states), ptr(self.next_states), ptr(self.actions),
-                                       ptr(self.rewards), ptr(self.dones), ptr(phys), B, ptr(out["sprice"]),
-                                       ptr(out["sprocess"]), ptr(out["sgas"]), ptr(out["nprice"]),
-                                       ptr(out["nprocess"]), ptr(out["ngas"]), ptr(out["act"]), ptr(out["rew"]),
-                                       ptr(out["done"]), self._st()))
+        B = phys.numel()
+        out = self._batch_tensors(B)
+        lib.check(lib.mctsq_per_gather(*self._ring_ptrs(), ptr(phys), B, *self._batch_ptrs(out), self._st()))
         return out
 
     # ---- priority write-back ----------------------------------------------------------
     def update_priorities(self, idx, prio):
         """prio[idx[i]] = p[i] in order (last duplicate wins), idx are LOGICAL indices."""
+        if not torch.is_tensor(idx) or not idx.is_cuda:      # host indices: range-checked like deque indexing
+            hidx = np.asarray(idx.cpu() if torch.is_tensor(idx) else idx, dtype=np.int64)
+            if hidx.size and (hidx.min() < -self.size or hidx.max() >= self.size):
+                raise IndexError("deque index out of range")
+            idx = np.where(hidx < 0, hidx + self.size, hidx)
         idx = torch.as_tensor(idx, dtype=torch.int64).to(self.device).contiguous()
         prio = torch.as_tensor(prio, dtype=torch.float32).to(self.device).contiguous()
         if idx.numel() != prio.numel():

@@ -132,8 +132,8 @@ def fixed_point_sample(prio, u, alpha=0.6, beta=0.4, capacity=None):
     k = np.rint(np.asarray(u, dtype=np.float64) * 2.0 ** 53).astype(np.int64)   # u = k / 2^53 exactly
     tgt = np.array([(int(ki) * total) >> 53 for ki in k], dtype=np.uint64)
     idx = cum.searchsorted(tgt, side="right").astype(np.int64)     # first i with C_i > t
-    # N * p_i / sum(p), with sum(p) := M / 2^S
-    ratio = (np.float64(n) * p[idx]) * np.float64(2.0 ** shift) / np.float64(total)
+    # N * p_i / sum(p), with sum(p) := M / 2^S and p_i the clamped value the masses were made from
+    ratio = (np.float64(n) * np.minimum(p[idx], 256.0)) * np.float64(2.0 ** shift) / np.float64(total)
     w64 = pow_det(ratio, -beta)
     w64 = w64 / w64.max()
     return idx, w64.astype(np.float32), w64

@@ -157,3 +157,130 @@ def test_sharded_sampling_kernels_match_single_buffer_oracle():
         assert np.array_equal(idx.cpu().numpy() + lo, idx_or[d])
         assert np.array_equal(w.cpu().numpy(), w_or[d])
     assert (served == 1).all()
+
+
+@pytest.mark.parametrize("tag", ["wrap", "partial"])
+def test_fused_sample_batch_equals_sample_then_gather(tag):
+    """mctsq_per_sample_batch (one launch) == mctsq_per_sample followed by mctsq_per_gather, bit for bit,
+    twice in a row on the same workspace (the normalisation ticket must return to zero)."""
+    z = np.load(os.path.join(GOLDEN, "per_cases.npz"))
+    buf = _build(tag, z)
+    for rep, n in enumerate((64, 33)):
+        u = np.random.RandomState(100 + rep).random_sample(n)
+        idx, phys, w = buf.sample_indices(u)
+        ref = buf.gather(phys)
+        batch, w2, idx2, phys2 = buf.sample_batch(u)
+        assert torch.equal(idx, idx2) and torch.equal(phys, phys2) and torch.equal(w, w2)
+        for k in ref:
+            assert torch.equal(ref[k], batch[k]), k
+        assert float(w2.max()) == 1.0
+
+
+def test_sync_free_shard_protocol_matches_single_buffer_oracle():
+    """shard_select + sample_shard (device-side compaction, device-side totals, fused gather): the rows every
+    rank serves, in draw order, equal the single-buffer oracle's; padding rows are neutral; a provision that is
+    too small is counted, not silently truncated."""
+    from mcts_q_amd.per import DevicePER
+    cap, B, world = 3000, 256, 2
+    rng = np.random.RandomState(19)
+    sizes = [cap, 1700]
+    prios = [np.abs(rng.standard_normal(n)).astype(np.float32) for n in sizes]
+    prios[1][::7] = 0.0
+    shards = []
+    for n, pr in zip(sizes, prios):
+        s = DevicePER(cap, mass_capacity=world * cap)
+        s.push_rows(_rows(n, 10000 * len(shards)), np.arange(n) % 5, np.arange(n, dtype=np.float32), _rows(n, 7), np.zeros(n))
+        s.update_priorities(np.arange(n), pr)
+        shards.append(s)
+    u = rng.random_sample(B)
+    ms = torch.stack([s.mass_and_size() for s in shards])
+    masses, nsz = ms[:, 0].contiguous(), ms[:, 1].contiguous()
+    assert nsz.tolist() == sizes
+    concat = np.concatenate(prios).astype(np.float64)
+    idx_or, w_or, _ = per_numpy.fixed_point_sample(concat, u, capacity=world * cap)
+    bcap = 208
+    outs, gmax = [], torch.zeros(1, dtype=torch.float64, device="cuda")
+    for r, s in enumerate(shards):
+        targets, draw, count = s.shard_select(u, masses, r, bcap)
+        batch, idx, w64, wmax = s.sample_shard(targets, count, masses, nsz)
+        gmax = torch.maximum(gmax, wmax)
+        outs.append((draw, count, batch, idx, w64))
+    served = np.zeros(B, dtype=np.int64)
+    for r, (draw, count, batch, idx, w64) in enumerate(outs):
+        lo = sum(sizes[:r])
+        mine = np.nonzero((idx_or >= lo) & (idx_or < lo + sizes[r]))[0]
+        n = len(mine)
+        assert count.tolist() == [n, 0]
+        d = draw.cpu().numpy()
+        assert np.array_equal(d[:n], mine) and (d[n:] == -1).all()
+        served[d[:n]] += 1
+        li = idx.cpu().numpy()
+        assert np.array_equal(li[:n] + lo, idx_or[mine]) and (li[n:] == -1).all()
+        w = shards[r].normalize_weights(w64, gmax).cpu().numpy()
+        assert np.array_equal(w[:n], w_or[mine]) and (w[n:] == 0).all()
+        assert np.array_equal(batch["sprice"][:n, 0, 0].cpu().numpy().astype(np.int64), li[:n] + 10000 * r)
+        assert np.array_equal(batch["act"][:n].cpu().numpy(), li[:n] % 5)
+        # padding rows never touch the priorities
+        before = shards[r].logical_priorities().copy()
+        shards[r].update_priorities(idx[n:], torch.full((bcap - n,), 9.0, device="cuda"))
+        assert np.array_equal(shards[r].logical_priorities(), before)
+    assert (served == 1).all()
+    _, _, count = shards[0].shard_select(u, masses, 0, 32)
+    n0 = int(((idx_or >= 0) & (idx_or < sizes[0])).sum())
+    assert count.tolist() == [32, n0 - 32]
+
+
+def test_priority_above_the_mass_clamp():
+    """prio^alpha is clamped at 256 (include/mctsq_hip.h): a priority above ~1.03e4 is sampled as if it
+    were exactly at the clamp, and the IS weights are those of that law (oracle: the same clamp; reference law on
+    the clamped priorities)."""
+    from mcts_q_amd.per import DevicePER
+    n = 2000
+    rng = np.random.RandomState(4)
+    pr = np.abs(rng.standard_normal(n)).astype(np.float32)
+    pr[[5, 900]] = [3.0e6, 1.0e5]
+    buf = DevicePER(n)
+    buf.push_rows(_rows(n), np.zeros(n), np.zeros(n), _rows(n), np.zeros(n))
+    buf.update_priorities(np.arange(n), pr)
+    u = rng.random_sample(512)
+    idx, _, w = buf.sample_indices(u)
+    idx_or, w_or, _ = per_numpy.fixed_point_sample(pr.astype(np.float64), u, capacity=n)
+    assert np.array_equal(idx.cpu().numpy(), idx_or) and np.array_equal(w.cpu().numpy(), w_or)
+    clamped = np.minimum(pr.astype(np.float64), 256.0 ** (1 / 0.6))
+    idx_ref, w_ref = per_numpy.reference_sample(clamped, u)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.abs(w.cpu().numpy() - w_ref).max() <= 2e-7
+    assert (idx_or == 5).sum() > 20 and abs(int((idx_or == 5).sum()) - int((idx_or == 900).sum())) < 40
+
+
+@pytest.mark.parametrize("B", [1000, 6000])
+def test_update_priorities_paths_and_bounds(B):
+    """Single-launch path (B <= 4096) and two-launch path: duplicates (last wins), indices at and beyond `size` on
+    a ring that is not full (device tensors: skipped; host arrays: IndexError like deque indexing)."""
+    from mcts_q_amd.per import DevicePER
+    cap, n = 20000, 12000
+    rng = np.random.RandomState(B)
+    buf = DevicePER(cap)
+    buf.push_rows(_rows(n), np.zeros(n), np.zeros(n), _rows(n), np.zeros(n))
+    ref = per_numpy.RefPER(cap)
+    ref.prio = [1.0] * n
+    ref.items = list(range(n))
+    idx = rng.randint(0, n, size=B)
+    idx[1::5] = idx[0]
+    pr = np.abs(rng.standard_normal(B)).astype(np.float32)
+    buf.update_priorities(idx, pr)
+    ref.update_priorities(idx, pr)
+    assert np.array_equal(buf.logical_priorities(), np.asarray(ref.prio))
+    m_or, _ = per_numpy.masses(np.asarray(ref.prio), 0.6, per_numpy.mass_shift(cap))
+    tree = buf.tree.cpu().numpy().view(np.uint64)
+    assert np.array_equal(tree[:n], m_or) and int(buf.total_mass()) == int(m_or.sum())
+    # device indices outside [0, size) are ignored: no never-pushed slot becomes sampleable
+    bad = torch.tensor([n, cap - 1, -3, n - 1], device="cuda")
+    buf.update_priorities(bad, torch.tensor([5.0, 5.0, 5.0, 0.5], device="cuda"))
+    ref.update_priorities([n - 1], [np.float32(0.5)])
+    assert np.array_equal(buf.logical_priorities(), np.asarray(ref.prio))
+    assert not buf.tree.cpu().numpy().view(np.uint64)[n:cap].any()
+    with pytest.raises(IndexError):
+        buf.update_priorities(np.array([n]), np.array([1.0], dtype=np.float32))
+    buf.update_priorities(np.array([-1]), np.array([0.125], dtype=np.float32))    # deque[-1] = newest
+    assert buf.logical_priorities()[-1] == 0.125

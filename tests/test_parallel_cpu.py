@@ -1,7 +1,7 @@
 """CPU, world_size 2 over gloo: the host logic of the data-parallel path (mcts_q_amd/parallel.py).
 
 The kernels cannot run here, so each rank's shard is an oracle-backed stand-in with the DevicePER
-shard interface (total_mass / shard_targets / sample_at / normalize_weights); what is under test is
+shard interface (mass_and_size / shard_select / sample_shard / normalize_weights); what is under test is
 the orchestration: mass all-gather, ownership of the shared draws, global N / mass / max in the IS
 weights, loss scaling + one SUM all-reduce reproducing the single-process global-batch gradient."""
 import os
@@ -49,10 +49,30 @@ class OracleShard:
     def sample_at(self, targets, n_total, mass_total, beta=0.4):
         tg = targets.numpy().astype(np.uint64)
         idx = self.cum.searchsorted(tg, side="right").astype(np.int64)
-        ratio = (np.float64(n_total) * self.p[idx]) * np.float64(2.0 ** self.shift) / np.float64(mass_total)
+        ratio = (np.float64(n_total) * np.minimum(self.p[idx], 256.0)) * np.float64(2.0 ** self.shift) / np.float64(mass_total)
         w64 = per_numpy.pow_det(ratio, -beta) if len(idx) else np.zeros(0)
         wmax = torch.tensor([w64.max() if len(idx) else 0.0], dtype=torch.float64)
         return torch.from_numpy(idx), torch.from_numpy(idx.copy()), torch.from_numpy(np.asarray(w64)), wmax
+
+    # ---- the sync-free protocol (DevicePER.mass_and_size / shard_select / sample_shard) --------------
+    def mass_and_size(self):
+        return torch.tensor([int(self.cum[-1]), len(self.prio)], dtype=torch.int64)
+
+    def shard_select(self, u, shard_mass, rank, bcap):
+        loc, mine = self.shard_targets(np.asarray(u), shard_mass, rank)
+        pos = np.nonzero(mine.numpy())[0]
+        kept = min(len(pos), bcap)
+        targets, draw = torch.zeros(bcap, dtype=torch.int64), torch.full((bcap,), -1, dtype=torch.int32)
+        targets[:kept] = loc[pos[:kept]]
+        draw[:kept] = torch.from_numpy(pos[:kept].astype(np.int32))
+        return targets, draw, torch.tensor([kept, len(pos) - kept], dtype=torch.int32)
+
+    def sample_shard(self, targets, count, shard_mass, shard_size, beta=0.4):
+        n, bcap = int(count[0]), targets.numel()
+        idx, _, w64, wmax = self.sample_at(targets[:n], float(shard_size.sum()), float(sum(int(m) for m in shard_mass.tolist())), beta)
+        idx_p, w_p = torch.full((bcap,), -1, dtype=torch.int64), torch.zeros(bcap, dtype=torch.float64)
+        idx_p[:n], w_p[:n] = idx, w64
+        return dict(rows=idx_p.clone()), idx_p, w_p, wmax
 
     def normalize_weights(self, w64, wmax):
         return (w64 / wmax).float()
@@ -78,17 +98,28 @@ def _worker(rank, world, port, outdir):
         lo = sum(sizes[:rank])
         shard = OracleShard(prio_all[lo:lo + sizes[rank]], mass_capacity=world * cap)
         u = parallel.shared_uniforms(np.random.RandomState(7), B)           # same seed on every rank
-        out = parallel.sharded_sample(shard, u, group=dist.group.WORLD)
+        assert parallel.draw_capacity(B, world) == 64 and parallel.draw_capacity(1024, 8) == 256
+        sampler = parallel.ShardedSampler(shard, dist.group.WORLD)
+        out = sampler.sample(u)
         # ---- single-buffer oracle over the concatenation ---------------------------------------
         concat = np.concatenate([prio_all[:sizes[0]], prio_all[sizes[0]:sizes[0] + sizes[1]]])
         idx_or, w_or, _ = per_numpy.fixed_point_sample(concat, u, capacity=world * cap)
         mine = (idx_or >= lo) & (idx_or < lo + sizes[rank])
-        assert np.array_equal(out["draw"].numpy(), np.nonzero(mine)[0])
-        assert np.array_equal(out["idx"].numpy() + lo, idx_or[mine])
-        assert np.array_equal(out["w"].numpy(), w_or[mine])                 # global N, mass and max
-        assert out["n_global"] == sum(sizes) and out["batch_global"] == B
-        counts = torch.tensor([len(out["draw"])]); dist.all_reduce(counts)
+        n = int(mine.sum())
+        assert out["count"].tolist() == [n, 0] and out["batch_global"] == B
+        assert out["idx"].numel() == sampler.bcap == 64                        # fixed provision, padded
+        assert np.array_equal(out["draw"].numpy()[:n], np.nonzero(mine)[0]) and (out["draw"].numpy()[n:] == -1).all()
+        assert np.array_equal(out["idx"].numpy()[:n] + lo, idx_or[mine]) and (out["idx"].numpy()[n:] == -1).all()
+        assert np.array_equal(out["w"].numpy()[:n], w_or[mine])             # global N, mass and max
+        assert (out["w"].numpy()[n:] == 0).all()                            # padding rows carry no weight
+        counts = out["count"][:1].clone().long(); dist.all_reduce(counts)
         assert int(counts) == B                                              # every draw served exactly once
+        sampler.sample(u)                                                    # the lagged counter check passes
+        # a provision that is too small is reported one step later
+        tight = parallel.ShardedSampler(shard, dist.group.WORLD, bcap=16)
+        tight.sample(u)
+        with pytest.raises(RuntimeError, match="provision"):
+            tight.sample(u)
 
         # ---- gradient: local draws, loss scaled by B_local/B, one SUM all-reduce ------------------
         cfg = dict(price="gru", process="conv", gas="mlp", act="relu", flavor="per")
@@ -135,4 +166,4 @@ def test_single_rank_path_equals_plain_sampling():
     out = parallel.sharded_sample(OracleShard(prio, 500), u, group=None)
     idx_or, w_or, _ = per_numpy.fixed_point_sample(prio, u, capacity=500)
     assert np.array_equal(out["idx"].numpy(), idx_or) and np.array_equal(out["w"].numpy(), w_or)
-    assert np.array_equal(out["draw"].numpy(), np.arange(32))
+    assert np.array_equal(out["draw"].numpy(), np.arange(32)) and out["count"].tolist() == [32, 0]

@@ -11,7 +11,7 @@ from bench import seeded_net
 combo = sys.argv[1] if len(sys.argv) > 1 else "gru/gru/gru"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-N = 200_000
+N = int(os.environ.get("MCTSQ_REPLAY", "1000000"))
 pe, pr, ga = combo.split("/")
 cfg = dict(price=pe, process=pr, gas=ga, act="relu", flavor="per")
 spec = NetSpec.from_cfg(cfg)
@@ -23,8 +23,7 @@ buf.push_rows(torch.rand(N, 91, device="cuda"), torch.randint(0, 5, (N,), device
 buf.update_priorities(torch.arange(N, device="cuda"), torch.rand(N, device="cuda") + 0.01)
 u = torch.from_numpy(np.random.RandomState(0).random_sample((K + 10, B))).cuda()
 def step(i):
-    idx, phys, w = buf.sample_indices(u[i])
-    batch = buf.gather(phys)
+    batch, w, idx, _ = buf.sample_batch(u[i])
     abs_td = L.compute_grad(batch, w)
     L.apply_grad(tau=0.005)
     buf.update_priorities(idx, abs_td)
