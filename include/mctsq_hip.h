@@ -255,6 +255,20 @@ int mctsq_per_gather(const float* d_states, const float* d_next_states, const in
                      void* stream);
 int64_t mctsq_per_workspace_bytes(int64_t capacity, int64_t B);
 
+/* ---- mctsq_per_sample without a workspace argument, allocating nothing.  NO counterpart in the reference: it
+ * exists for callers that cannot allocate or carry scratch memory - code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  Same inputs, outputs and results as mctsq_per_sample; the sampling
+ * workspace (control words + one raw fp64 weight per draw) is a fixed array inside the library's device image:
+ * 128.06 KiB per GPU, held until the process ends, so B <= mctsq_per_sample_noalloc_max_draws() (16384) - larger
+ * batches are refused with an error.  All calls on one GPU share that array: calls that overlap in time on one
+ * GPU (different streams) race; serialise them.  The first call on a device does a one-time set-up (symbol
+ * lookup + a 64-byte memset on `stream`); make it outside graph capture. */
+int64_t mctsq_per_sample_noalloc_max_draws(void);
+int mctsq_per_sample_noalloc(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
+                             int64_t size, const double* d_u, int64_t B, double alpha, double beta,
+                             int64_t mass_capacity, int64_t* d_idx, int64_t* d_phys, float* d_w,
+                             double* d_wmax, void* stream);
+
 #define MCTSQ_STATE_ROW 96 /* floats per stored state record (91 used) */
 
 #ifdef __cplusplus

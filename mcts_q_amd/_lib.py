@@ -59,6 +59,9 @@ SIGNATURES = {
     "mctsq_per_shard_select": (_i32, [_vp, _i64, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "mctsq_per_sample_shard": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _f64, _f64, _i64, _vp, _vp, _i32,
                                       _vp, _vp, _vp, _vp] + [_vp] * 14 + [_vp, _i64, _vp]),
+    "mctsq_per_sample_noalloc_max_draws": (_i64, []),
+    "mctsq_per_sample_noalloc": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _f64, _f64, _i64, _vp, _vp, _vp, _vp,
+                                        _vp]),
     "mctsq_per_update": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _f64, _i64, _vp]),
     "mctsq_per_total_mass": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "mctsq_per_shard_targets": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -708,3 +708,60 @@ int launch_per_gather(const PerGatherArgs& a, hipStream_t st) {
 }
 
 }  // namespace mctsq
+
+// ------------------------------------------------------------------ sampling without a workspace argument
+// mctsq_per_sample_noalloc (include/mctsq_hip.h): mctsq_per_sample for callers that cannot allocate or carry a
+// workspace (HIP graph capture, serving loops, harnesses that forbid hipMalloc).  The sampling workspace -- the
+// control words and one raw fp64 weight per draw -- lives in this file-scope device array instead; every GPU the
+// library runs on holds its own copy (64 B + 8 B x 16384 draws = 128.06 KiB) until the process ends.
+// `noalloc_scratch` is only a host-side stand-in for the array: the device address comes from
+// hipGetSymbolAddress, once per device, and only that pointer is handed to kernels and memsets.
+using namespace mctsq;
+
+constexpr int64_t NOALLOC_MAX_DRAWS = SMP_FUSED_NORM_MAX;
+static __device__ __align__(256) unsigned char noalloc_scratch[PER_WS_CTRL_BYTES + 8 * NOALLOC_MAX_DRAWS];
+
+namespace {
+std::mutex g_noalloc_mu;
+void* g_noalloc_ptr[64];                 // per device ordinal: address of that device's copy of noalloc_scratch
+
+int noalloc_scratch_ptr(hipStream_t st, void** out) {
+    int dev = 0;
+    MCTSQ_HIP(hipGetDevice(&dev));
+    MCTSQ_CHECK(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_noalloc_mu);
+    if (!g_noalloc_ptr[dev]) {
+        void* p = nullptr;
+        MCTSQ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(noalloc_scratch)));
+        MCTSQ_CHECK(p != nullptr, "hipGetSymbolAddress returned NULL for the sampling scratch");
+        // the control words must start at zero; every launch leaves them zero again
+        MCTSQ_HIP(hipMemsetAsync(p, 0, PER_WS_CTRL_BYTES, st));
+        g_noalloc_ptr[dev] = p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" int64_t mctsq_per_sample_noalloc_max_draws(void) { return NOALLOC_MAX_DRAWS; }
+
+extern "C" int mctsq_per_sample_noalloc(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
+                                        int64_t size, const double* d_u, int64_t B, double alpha, double beta,
+                                        int64_t mass_capacity, int64_t* d_idx, int64_t* d_phys, float* d_w,
+                                        double* d_wmax, void* stream) {
+    MCTSQ_CHECK(capacity >= 1 && size >= 1 && size <= capacity && head >= 0 && head < capacity &&
+                    (size == capacity || head == 0), "bad ring geometry (capacity %lld, head %lld, size %lld)",
+                (long long)capacity, (long long)head, (long long)size);
+    MCTSQ_CHECK(mass_capacity >= capacity && mass_capacity <= (int64_t)1 << 36, "mass_capacity out of range");
+    MCTSQ_CHECK(B >= 0, "negative batch");
+    MCTSQ_CHECK(B <= NOALLOC_MAX_DRAWS, "mctsq_per_sample_noalloc serves at most %lld draws per call (got %lld): its "
+                "scratch is a fixed device array; use mctsq_per_sample with a workspace for more",
+                (long long)NOALLOC_MAX_DRAWS, (long long)B);
+    if (B == 0) return 0;
+    MCTSQ_CHECK(d_tree && d_prio && d_u && d_idx && d_phys && d_w, "NULL device pointer");
+    void* scratch = nullptr;
+    if (noalloc_scratch_ptr((hipStream_t)stream, &scratch)) return -1;
+    return launch_per_sample((const unsigned long long*)d_tree, d_prio, capacity, head, size, d_u, B, alpha, beta,
+                             mass_capacity, d_idx, d_phys, d_w, d_wmax, scratch, nullptr, (hipStream_t)stream);
+}
+
