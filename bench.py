@@ -307,7 +307,8 @@ def main():
 
             def train_step(i):
                 if world == 1:
-                    batch, w, idx, _ = buf.sample_batch(u_all[i])          # sample + IS weights + gather: one launch
+                    L.step(buf, u_all[i], tau=0.005)                       # DQNModel.update() + target sync: one call
+                    return
                 else:
                     smp = sampler.sample(u_all[i])                         # no host read of device memory
                     batch, w, idx = smp["batch"], smp["w"], smp["idx"]

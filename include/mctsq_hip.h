@@ -122,8 +122,10 @@ int mctsq_encoder_forward(const mctsq_encoder_desc* enc, const float* d_enc_para
  *   Outputs: d_grad [total] fp32 (overwritten, UNclipped, already divided by B as the mean
  *   does), d_loss [1] fp32, d_abs_td [B] fp32 (new priorities, dqn_per.py:474),
  *   d_qsa [B] and d_target [B] fp32 (optional, may be NULL).
- * loss_scale: multiply the loss gradient (use 1/world for data-parallel sum-all-reduce with a
- * per-rank B that is 1/world of the global batch... see INTEGRATION.md); normally 1. */
+ * loss_scale: multiplies the loss AND its gradient.  Data-parallel: pass B_local / B_global on every rank and
+ * all-reduce(SUM) gradient and loss - both then are those of the global batch mean; else 1.
+ * Besides `stream`, the call uses one helper stream per (device, stream), forked from and joined back to
+ * `stream` with events inside the call (also on every error path). */
 int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B);
 int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
                    const float* d_sprice, const float* d_sprocess, const float* d_sgas,
@@ -132,6 +134,60 @@ int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float
                    const float* d_isw, float gamma, float loss_scale, int64_t B, float* d_grad,
                    float* d_loss, float* d_abs_td, float* d_qsa, float* d_target, void* d_ws,
                    int64_t ws_bytes, void* stream);
+
+/* ---- the same step with the weights prepared once per parameter change instead of inside every call.
+ * mctsq_dqn_prepare fills, in one launch for the shipped gru/gru/gru network: d_prep_policy and d_prep_target
+ * (mctsq_q_prepared_bytes each; the mctsq_q_prepare layout, so the policy's buffer also serves
+ * mctsq_q_forward_prepared between learner steps) and d_prep_bwd (mctsq_dqn_prepared_bwd_bytes: the fragments
+ * the backward pass multiplies by).  Call it after every change of the parameters (Adam, Polyak, load).
+ * mctsq_dqn_grad_prepared = mctsq_dqn_grad on those buffers; additionally, if d_sumsq_parts is not NULL
+ * (mctsq_dqn_grad_sumsq_parts doubles), it receives the pieces of the gradient's sum of squares, produced for
+ * free by the ordered reduction, *n_sumsq_parts their count: pass both to mctsq_clip_adam_polyak_ex, which
+ * then needs no pass over the gradient for the norm (single GPU; a data-parallel step all-reduces the gradient
+ * in between and passes NULL). */
+int64_t mctsq_dqn_prepared_bwd_bytes(const mctsq_net_desc* net);
+int mctsq_dqn_prepare(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
+                      void* d_prep_policy, void* d_prep_target, void* d_prep_bwd, void* stream);
+int64_t mctsq_dqn_grad_sumsq_parts(const mctsq_net_desc* net);
+int mctsq_dqn_grad_prepared(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
+                            const void* d_prep_policy, const void* d_prep_target, const void* d_prep_bwd,
+                            const float* d_sprice, const float* d_sprocess, const float* d_sgas,
+                            const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                            const int32_t* d_act, const float* d_rew, const float* d_done,
+                            const float* d_isw, float gamma, float loss_scale, int64_t B, float* d_grad,
+                            float* d_loss, float* d_abs_td, float* d_qsa, float* d_target,
+                            double* d_sumsq_parts, int64_t* n_sumsq_parts, void* d_ws, int64_t ws_bytes,
+                            void* stream);
+
+/* ---- DQNModel.update() (dqn_per.py:401-476) as ONE call on a device-resident replay ring: sample (uniforms
+ * d_u) -> batch assembly -> loss + backward -> clip_grad_norm_ + Adam (+ Polyak when tau >= 0; the reference syncs
+ * the target right after update(), mctsq_config_mcts_per.py:181) -> weight fragments of the new parameters ->
+ * priority write-back.  Same kernels, same results as mctsq_per_sample_batch, mctsq_dqn_grad_prepared,
+ * mctsq_clip_adam_polyak_ex, mctsq_dqn_prepare and mctsq_per_update called in that order; it exists because at
+ * the training batch size the HOST (five binding calls, per-step buffers) bounds the step otherwise.
+ * All pointers are device pointers owned by the caller; d_ws: mctsq_per_dqn_step_workspace_bytes, 256-byte
+ * aligned (the sampled batch, indices, weights, |td| and all scratch live there); d_loss [1] fp32 out;
+ * d_gnorm [1] fp32 out (optional); d_wmax [1] fp64 out (optional).  adam_step is 1-based. */
+typedef struct {
+    /* replay ring (see "prioritized replay" below) */
+    uint64_t* d_tree; double* d_prio; int32_t* d_stamp;
+    const float* d_states; const float* d_next_states; const int32_t* d_actions; const float* d_rewards;
+    const float* d_dones;
+    int64_t capacity, head, size, mass_capacity;
+    double alpha, beta;
+    void* d_per_ws; int64_t per_ws_bytes;
+    /* learner state: flat parameter-layout buffers and the prepared fragments (mctsq_dqn_prepare) */
+    float* d_params; float* d_target_params; float* d_grad; float* d_m; float* d_v;
+    void* d_prep_policy; void* d_prep_target; void* d_prep_bwd;
+    double gamma, lr, beta1, beta2, eps, max_norm, tau;
+    int64_t adam_step;
+    /* this step */
+    const double* d_u; int64_t B;
+    float* d_loss; float* d_gnorm; double* d_wmax;
+    void* d_ws; int64_t ws_bytes;
+} mctsq_step_args;
+int64_t mctsq_per_dqn_step_workspace_bytes(const mctsq_net_desc* net, int64_t B);
+int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_args* args, void* stream);
 
 /* ---- clip_grad_norm_(max_norm) + Adam.step + Polyak target update (dqn_per.py:471-472,
  * 510-516) over the flat buffers, n floats each.  step is 1-based.  tau < 0 skips the target
@@ -143,6 +199,11 @@ int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, flo
                            float* d_target, int64_t n, int64_t step, double lr, double beta1,
                            double beta2, double eps, double max_norm, double tau, float* d_gnorm,
                            void* d_ws, int64_t ws_bytes, void* stream);
+int mctsq_clip_adam_polyak_ex(float* d_params, const float* d_grad, float* d_m, float* d_v,
+                              float* d_target, int64_t n, int64_t step, double lr, double beta1,
+                              double beta2, double eps, double max_norm, double tau, float* d_gnorm,
+                              const double* d_sumsq_parts, int64_t nparts, void* d_ws, int64_t ws_bytes,
+                              void* stream);
 /* Polyak / hard sync alone: target <- tau*policy + (1-tau)*target (dqn_per.py:515-516). */
 int mctsq_polyak(const float* d_params, float* d_target, int64_t n, double tau, void* stream);
 

@@ -25,6 +25,19 @@ class NetDesc(C.Structure):
 _vp, _i64, _i32, _f32, _f64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double
 _ND = C.POINTER(NetDesc)
 
+
+class StepArgs(C.Structure):
+    """mctsq_step_args (include/mctsq_hip.h)."""
+    _fields_ = ([(n, _vp) for n in ("d_tree", "d_prio", "d_stamp", "d_states", "d_next_states", "d_actions",
+                                    "d_rewards", "d_dones")]
+                + [(n, _i64) for n in ("capacity", "head", "size", "mass_capacity")]
+                + [("alpha", _f64), ("beta", _f64), ("d_per_ws", _vp), ("per_ws_bytes", _i64)]
+                + [(n, _vp) for n in ("d_params", "d_target_params", "d_grad", "d_m", "d_v", "d_prep_policy",
+                                      "d_prep_target", "d_prep_bwd")]
+                + [(n, _f64) for n in ("gamma", "lr", "beta1", "beta2", "eps", "max_norm", "tau")]
+                + [("adam_step", _i64), ("d_u", _vp), ("B", _i64), ("d_loss", _vp), ("d_gnorm", _vp), ("d_wmax", _vp),
+                   ("d_ws", _vp), ("ws_bytes", _i64)])
+
 # name -> (restype, argtypes); every symbol declared in include/mctsq_hip.h
 SIGNATURES = {
     "mctsq_abi_version": (_i32, []),
@@ -43,6 +56,15 @@ SIGNATURES = {
     "mctsq_dqn_grad_workspace_bytes": (_i64, [_ND, _i64]),
     "mctsq_dqn_grad": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32,
                               _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mctsq_dqn_prepared_bwd_bytes": (_i64, [_ND]),
+    "mctsq_dqn_prepare": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mctsq_dqn_grad_sumsq_parts": (_i64, [_ND]),
+    "mctsq_dqn_grad_prepared": (_i32, [_ND, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mctsq_per_dqn_step_workspace_bytes": (_i64, [_ND, _i64]),
+    "mctsq_per_dqn_step": (_i32, [_ND, C.POINTER(StepArgs), _vp]),
+    "mctsq_clip_adam_polyak_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64,
+                                         _f64, _vp, _vp, _i64, _vp, _i64, _vp]),
     "mctsq_optim_workspace_bytes": (_i64, []),
     "mctsq_clip_adam_polyak": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64,
                                       _f64, _vp, _vp, _i64, _vp]),

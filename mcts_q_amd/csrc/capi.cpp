@@ -193,6 +193,9 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     if (head_bf16_layout(L)) ha.wprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L);
 
     if (fused_gru_head_applicable(ga, ha)) {                 // shipped default: one launch
+        // (measured at the training batch, 64 tiles: the per-window kernels + head kernel take 38 + 9 us against 53
+        // for this kernel's activation-saving variant, which spills registers at two waves per SIMD, but policy and
+        // target forward then oversubscribe the CUs and the step as a whole gets slower: 0.221 vs 0.213 ms)
         if (!save) ga.feats = nullptr;                       // training keeps the feature rows for the head backward
         if (launch_gru3_head_fwd(ga, ha, save, st)) return -1;
         if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));

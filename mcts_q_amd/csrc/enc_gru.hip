@@ -2,6 +2,7 @@
 // one workgroup (4 waves) per (16-sample tile, GRU slot), features written to the [Bp,192] buffer
 // the head kernel reads.  The all-GRU default goes through fused_gru_head.hip instead.
 #include "gru_core.hpp"
+#include "prepare_core.hpp"
 
 namespace mctsq {
 
@@ -26,17 +27,12 @@ __global__ __launch_bounds__(256) void gru_enc_fwd_kernel(GruFwdArgs args) {
     g.fin2(s, L, args.feats + row0 * FEAT + s.out_col, FEAT, row0, g.lnwj, g.lnbj);
 }
 
-// one thread per (slot, wave, gate, K chunk, lane): 8 consecutive weights -> 3 x 8 bf16
+// one thread per (slot, wave, gate, K chunk, lane): 8 consecutive weights -> 3 x 8 bf16 (prepare_core.hpp)
 struct GruPrepArgs { const float* whh[3]; u32x4* out; };
 __global__ __launch_bounds__(256) void gru_prepare_kernel(GruPrepArgs a) {
     const int tid = blockIdx.x * 256 + threadIdx.x;           // grid = n * 6 blocks of 256
-    const int lane = tid & 63, c = (tid >> 6) & 1, rest = tid >> 7, g = rest % 3, wq = (rest / 3) & 3, slot = rest / 12;
-    const int jl = lane & 15, q = lane >> 4;
-    const float4* pw = reinterpret_cast<const float4*>(a.whh[slot] + (int64_t)(g * E + 16 * wq + jl) * E + 32 * c + 8 * q);
-    u32x4 hi, mid, lo;
-    split8(pw[0], pw[1], hi, mid, lo);
-    u32x4* o = a.out + (int64_t)slot * (GRU_PREP_BYTES / 16) + (((wq * 3 + g) * 2 + c) * 3) * 64 + lane;
-    o[0] = hi; o[64] = mid; o[128] = lo;
+    const int slot = tid / 1536;
+    prep_gru_fwd(a.whh[slot], a.out + (int64_t)slot * (GRU_PREP_BYTES / 16), tid - slot * 1536);
 }
 
 int launch_gru_prepare(const float* const whh[3], int n, void* prep, hipStream_t st) {

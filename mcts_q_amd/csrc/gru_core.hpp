@@ -334,6 +334,7 @@ struct GruWave {
             rg[r] = sigmoid_fast(accr[r]);
             zg[r] = sigmoid_fast(accz[r]);
         }
+        f32x4 svn, svhn, svh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
@@ -345,14 +346,20 @@ struct GruWave {
             L.hb[0][nxt][i * HLD + j] = (unsigned short)(u0 >> 16);
             L.hb[1][nxt][i * HLD + j] = (unsigned short)(u1 >> 16);
             L.hb[2][nxt][i * HLD + j] = (unsigned short)(u2 >> 16);
-            if (SAVE) {
-                // uniform 64-bit base (scalar registers) + 32-bit lane offset + constant: no vector address math
-                const int64_t ub = ((int64_t)t * Bp + row0) * E;
-                const int lo = (4 * q + r) * E + j;
-                (s.sv_r + ub)[lo] = rg[r]; (s.sv_z + ub)[lo] = zg[r]; (s.sv_n + ub)[lo] = ng; (s.sv_hn + ub)[lo] = hn;
-                (s.sv_h + ub + Bp * E)[lo] = hnew;
-            }
+            if (SAVE) { svn[r] = ng; svhn[r] = hn; svh[r] = hnew; }
             hh[cur][r] = hnew;
+        }
+        if (SAVE) {
+            // training record, lane-major (kernels.hpp: GruSlot): the lane's four rows of one unit are one 16-byte
+            // store, a wave's store instruction one contiguous KB.  Uniform 64-bit base (scalar registers) + 32-bit
+            // lane offset: no vector address math
+            const int64_t ub = (((int64_t)t * (Bp / TILE) + row0 / TILE) * 4 + wq) * 256;
+            const int lo = lane * 4;
+            *reinterpret_cast<f32x4*>(s.sv_r + ub + lo) = (f32x4){rg[0], rg[1], rg[2], rg[3]};
+            *reinterpret_cast<f32x4*>(s.sv_z + ub + lo) = (f32x4){zg[0], zg[1], zg[2], zg[3]};
+            *reinterpret_cast<f32x4*>(s.sv_n + ub + lo) = svn;
+            *reinterpret_cast<f32x4*>(s.sv_hn + ub + lo) = svhn;
+            *reinterpret_cast<f32x4*>(s.sv_h + ub + Bp * E + lo) = svh;
         }
     }
 

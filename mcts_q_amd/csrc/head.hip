@@ -6,6 +6,7 @@
 #include "device_utils.hpp"
 #include "kernels.hpp"
 #include "head_core.hpp"
+#include "prepare_core.hpp"
 
 namespace mctsq {
 
@@ -140,23 +141,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
 // (tile, chunk c) holds W[16 tile + jl][32c + 8q .. +7]; rows >= A of the output layer are zero.
 __global__ __launch_bounds__(256) void head_prepare_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
                                                            const float* __restrict__ w2, int A, u32x4* __restrict__ out) {
-    const int tid = blockIdx.x * 256 + threadIdx.x, lane = tid & 63, fg = tid >> 6;
-    if (fg >= 48 + 32 + 4) return;
-    const int jl = lane & 15, q = lane >> 4;
-    const float* w;
-    int K, tile, c, base;
-    bool valid = true;
-    if (fg < 48) { w = w0; K = FEAT; tile = fg / 6; c = fg % 6; base = fg * 3; }
-    else if (fg < 80) { const int f = fg - 48; w = w1; K = 128; tile = f / 4; c = f % 4; base = H0_FR + f * 3; }
-    else { const int f = fg - 80; w = w2; K = 128; tile = 0; c = f; base = H0_FR + H1_FR + f * 3; valid = jl < A; }
-    float4 a = make_float4(0, 0, 0, 0), b = a;
-    if (valid) {
-        const float4* p = reinterpret_cast<const float4*>(w + (int64_t)(16 * tile + jl) * K + 32 * c + 8 * q);
-        a = p[0]; b = p[1];
-    }
-    u32x4 hi, mid, lo;
-    split8(a, b, hi, mid, lo);
-    out[(base + 0) * 64 + lane] = hi; out[(base + 1) * 64 + lane] = mid; out[(base + 2) * 64 + lane] = lo;
+    prep_head_fwd(w0, w1, w2, A, out, blockIdx.x * 256 + threadIdx.x);
 }
 int launch_head_prepare(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st) {
     MCTSQ_CHECK(w0 && w1 && w2 && prep && A >= 1 && A <= 16, "head prepare: bad arguments");

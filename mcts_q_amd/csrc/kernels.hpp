@@ -11,19 +11,28 @@ struct GruSlot {
     const void* wprep;                   // W_hh split into bf16 planes in fragment order (gru_prepare_kernel)
     const void* wprep_t;                 // training: W_hh as B operand of delta . W_hh, split, lane-major (gru_prepare_bwd_kernel)
     int S, Fd, F, tf, out_col;
-    // training-time activation record (NULL for inference), Bp = padded batch
-    float* sv_h;                         // [S+1][Bp][64]: block 0 = h_{-1} = 0, block t+1 = h_t
-    float *sv_r, *sv_z, *sv_n, *sv_hn;   // [S][Bp][64]
+    // training-time activation record (NULL for inference), Bp = padded batch.  The per-step records are LANE-MAJOR:
+    // [step][tile = row / 16][wave 4][lane 64][r 4] holds the value of row 16 tile + 4 (lane >> 4) + r, unit
+    // 16 wave + (lane & 15) -- the forward's and the backward's own register layout, so both move a step's record
+    // with one 16-byte access per lane (gru_rec_index() addresses single elements)
+    float* sv_h;                         // [S+1] step blocks: block 0 = h_{-1} = 0, block t+1 = h_t
+    float *sv_r, *sv_z, *sv_n, *sv_hn;   // [S] step blocks
     float* sv_score;                     // [S][Bp], log2 units
     float* sv_stat;                      // [Bp][4] = running max, running sum, LN mean, LN rstd
     float* sv_pool;                      // [Bp][64] pooled vector before LayerNorm
     float* sv_x;                         // [S][Bp][8] time-major window incl. time features, zero padded
     // backward outputs (learner.hip)
-    float* bw_g;                         // [S][Bp][256] = d(pre-activation) r | z | n | n*r
+    float* bw_g;                         // [S][tile][4 = d(pre-activation) r | z | n | n*r] lane-major blocks of 1024
     float* bw_dsc;                       // [S][Bp] d(score)
     float* bw_p;                         // [Bp][64] dfeat * xhat (LayerNorm weight gradient terms)
     float* bw_aw;                        // [Bp/16][65] per-tile partials of the score Linear(64,1) gradient
 };
+// element (row, unit) of step block t of a lane-major record with Bp rows
+inline __host__ __device__ int64_t gru_rec_index(int64_t t, int64_t Bp, int64_t row, int unit) {
+    const int64_t tile = row >> 4;
+    const int i = (int)(row & 15);
+    return (((t * (Bp >> 4) + tile) * 4 + (unit >> 4)) * 64 + ((i >> 2) * 16 + (unit & 15))) * 4 + (i & 3);
+}
 struct GruFwdArgs {
     GruSlot slot[3];
     int nslots;

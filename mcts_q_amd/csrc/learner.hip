@@ -8,6 +8,12 @@
 // fixed order (bitwise reproducible, no float atomics).
 #include "device_utils.hpp"
 #include "learner.hpp"
+#include "prepare_core.hpp"
+#ifndef EXP_BWD
+#define EXP_BWD 0
+#endif
+
+#include <string.h>
 
 namespace mctsq {
 
@@ -152,11 +158,59 @@ __global__ __launch_bounds__(512) void head_bwd_bf16_kernel(HeadBwdArgs a) {
         h1[r] = a.sv_act[1][(row0 + 4 * q + r) * 128 + 16 * w + jl];
         h0[r] = a.sv_act[0][(row0 + 4 * q + r) * 128 + 16 * w + jl];
     }
+    // fused TD loss (dqn_per.py:455-467, 474): the arithmetic of td_loss_kernel for this tile's 16 rows
+    __shared__ float s_dq[TILE][DQ_LD];
+    __shared__ double s_loss[TILE];
+    if (a.fuse_td) {
+        const TdArgs& t = a.td;
+        if (tid < TILE) {
+            const int64_t i = row0 + tid;
+            float g = 0.0f;
+            int ac = -1;
+            double l = 0.0;
+            if (i < t.B) {
+                // the whole Q row travels with the action index (no dependent second round trip)
+                float qrow[DQ_LD];
+#pragma unroll
+                for (int c = 0; c < DQ_LD; ++c) qrow[c] = c < t.A ? t.q[i * t.A + c] : 0.0f;
+                ac = t.act[i];
+                const float rw = t.rew[i], qn = t.qnext[i], dn = t.done[i];
+                const bool ok = ac >= 0 && ac < t.A;
+                float qsa = 0.0f;
+#pragma unroll
+                for (int c = 0; c < DQ_LD; ++c) qsa = c == ac ? qrow[c] : qsa;
+                const float y = __fadd_rn(rw, __fmul_rn(__fmul_rn(t.gamma, qn), 1.0f - dn));
+                const float td = qsa - y;
+                const float w = t.isw[i];
+                l = (double)__fmul_rn(w, __fmul_rn(td, td));
+                g = ok ? t.grad_scale * w * td : 0.0f;
+                if (!ok) ac = -1;
+                t.abs_td[i] = fabsf(td);
+                if (t.qsa) t.qsa[i] = qsa;
+                if (t.target) t.target[i] = y;
+            }
+            s_loss[tid] = l;
+            float4* row = reinterpret_cast<float4*>(t.dq + i * DQ_LD);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 v = make_float4(0, 0, 0, 0);
+                if ((ac >> 2) == c) (&v.x)[ac & 3] = g;
+                row[c] = v;
+                *reinterpret_cast<float4*>(&s_dq[tid][4 * c]) = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int i = 0; i < TILE; ++i) sum += s_loss[i];
+            a.loss_parts[blockIdx.x] = sum;
+        }
+    }
     // dQ [16 x 16] -> planes, k padded to 32 with zeros
     {
         const int i = tid >> 5, c = tid & 31;
         unsigned u0 = 0, u1 = 0, u2 = 0;
-        if (c < DQ_LD) split3(a.dq[(row0 + i) * DQ_LD + c], u0, u1, u2);
+        if (c < DQ_LD) split3(a.fuse_td ? s_dq[i][c] : a.dq[(row0 + i) * DQ_LD + c], u0, u1, u2);
         pq[0][i * DQP + c] = (unsigned short)(u0 >> 16);
         pq[1][i * DQP + c] = (unsigned short)(u1 >> 16);
         pq[2][i * DQP + c] = (unsigned short)(u2 >> 16);
@@ -236,23 +290,7 @@ __global__ __launch_bounds__(512) void head_bwd_bf16_kernel(HeadBwdArgs a) {
 // one thread per (fragment group, lane): 8 k-values (output units) of one input column -> 3 x 8 bf16
 __global__ __launch_bounds__(256) void head_prepare_bwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
                                                                const float* __restrict__ w2, int A, u32x4* __restrict__ out) {
-    const int tid = blockIdx.x * 256 + threadIdx.x, lane = tid & 63, fg = tid >> 6;   // 8 + 32 + 48 groups
-    if (fg >= 88) return;
-    const int jl = lane & 15, q = lane >> 4;
-    const float* W;
-    int N, K, tile, c, base;
-    if (fg < 8) { W = w2; N = 128; K = A; tile = fg; c = 0; base = fg * 3; }
-    else if (fg < 40) { const int f = fg - 8; W = w1; N = 128; K = 128; tile = f >> 2; c = f & 3; base = TB2 + f * 3; }
-    else { const int f = fg - 40; W = w0; N = FEAT; K = 128; tile = f >> 2; c = f & 3; base = TB2 + TB1 + f * 3; }
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = 32 * c + 8 * q + e;
-        v[e] = k < K ? W[(int64_t)k * N + 16 * tile + jl] : 0.0f;
-    }
-    u32x4 hi, mid, lo;
-    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, mid, lo);
-    out[(base + 0) * 64 + lane] = hi; out[(base + 1) * 64 + lane] = mid; out[(base + 2) * 64 + lane] = lo;
+    prep_head_bwd(w0, w1, w2, A, out, blockIdx.x * 256 + threadIdx.x);
 }
 int launch_head_prepare_bwd(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st) {
     MCTSQ_CHECK(w0 && w1 && w2 && prep && A >= 1 && A <= 16, "head backward prepare: bad arguments");
@@ -297,10 +335,16 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     const int slot = blockIdx.x % args.nslots;
     const int64_t row0 = (int64_t)(blockIdx.x / args.nslots) * TILE;
     const GruSlot& s = args.slot[slot];
-    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6, jl = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, wq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), jl = lane & 15, q = lane >> 4;
     const int j = 16 * wq + jl;
     const int S = s.S;
     const int64_t Bp = args.Bp;
+    // lane-major records (kernels.hpp: GruSlot): block (t, tile, wave) is 256 floats, this lane's four rows one float4
+    const int64_t ntile = Bp / TILE, tile = row0 / TILE;
+    const int lo4 = lane * 4;
+    auto rec = [&](const float* base, int t) {
+        return *reinterpret_cast<const f32x4*>(base + (((int64_t)t * ntile + tile) * 4 + wq) * 256 + lo4);
+    };
 
     // W_hh as B operand of the delta . W_hh product (k = gate row, col = unit j): prepared split-bf16 fragments,
     // 6 K chunks x 3 planes resident in 72 VGPRs.  The product runs on the bf16 matrix instruction over the exact
@@ -347,13 +391,10 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         const float v = row16_sum(dpool[r] * pooled[r]);
         if (jl == 0) L.red[2][wq][4 * q + r] = v;
     }
-    for (int t0 = 0; t0 < S; t0 += 8) {                       // 32 loads in flight per lane, then the sums
-        float hv[8][4];
+    for (int t0 = 0; t0 < S; t0 += 8) {                       // 8 x 16 bytes in flight per lane, then the sums
+        f32x4 hv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                hv[u][r] = t0 + u < S ? s.sv_h[((int64_t)(t0 + u + 1) * Bp + row0 + 4 * q + r) * E + j] : 0.0f;
+        for (int u = 0; u < 8; ++u) hv[u] = t0 + u < S ? rec(s.sv_h, t0 + u + 1) : (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (t0 + u >= S) break;
@@ -373,19 +414,16 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     }
 
     // ---- BPTT ----------------------------------------------------------------------------
-    // The saved activations of step t-1 are fetched while step t's MFMA chain runs, so the
+    // The saved activations of the steps ahead are fetched while the current step's MFMA chain runs, so the
     // recurrence never waits on HBM/L2 latency.
-    struct StepIn { float rg, zg, ng, hn, hprev, sc; };
-    StepIn sb0[4], sb1[4], sb2[4];         // three steps of saved activations in flight (HBM latency > one step)
-    auto fetch = [&](StepIn (&d)[4], int t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = (int64_t)t * Bp + row0 + 4 * q + r;
-            const int64_t o = row * E + j;
-            d[r].rg = s.sv_r[o]; d[r].zg = s.sv_z[o]; d[r].ng = s.sv_n[o]; d[r].hn = s.sv_hn[o];
-            d[r].hprev = s.sv_h[o];                            // block t = h_{t-1}
-            d[r].sc = s.sv_score[row];
-        }
+    struct StepIn { f32x4 rg, zg, ng, hn, hprev; float sc[4]; };
+    StepIn sb0, sb1, sb2;                  // three steps of saved activations in flight (HBM latency > one step)
+    const float* scp = s.sv_score + row0 + 4 * q;
+    auto fetch = [&](StepIn& d, int t) {
+        d.rg = rec(s.sv_r, t); d.zg = rec(s.sv_z, t); d.ng = rec(s.sv_n, t); d.hn = rec(s.sv_hn, t);
+        d.hprev = rec(s.sv_h, t);                              // block t = h_{t-1}
+        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(scp + (int64_t)t * Bp);
+        d.sc[0] = sc4[0]; d.sc[1] = sc4[1]; d.sc[2] = sc4[2]; d.sc[3] = sc4[3];
     };
     fetch(sb0, S - 1);
     if (S >= 2) fetch(sb1, S - 2);
@@ -393,43 +431,53 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     // gradient of the score Linear(64,1): d_aw[j] = sum_{t,row} dsc * h_t[row][j], d_ab = sum dsc.  h_t is
     // the h_{t-1} operand of the step handled just before (the loop runs backwards); the tile's sums
     // go out as one partial, reduced over tiles in order by wgrad_reduce_kernel.
-    float hnext[4], daw = 0.0f, dab = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hnext[r] = s.sv_h[((int64_t)S * Bp + row0 + 4 * q + r) * E + j];
+    float daw = 0.0f, dab = 0.0f;
+    f32x4 hnext = rec(s.sv_h, S);
     float dhc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    auto bptt_step = [&](int t, StepIn (&cur)[4]) {
+    auto bptt_step = [&](int t, StepIn& cur) {
         const int buf = t & 1;
-        float zs[4], dhs[4];
+        float zs[4], dhs[4], dsc[4], at[4];
+        // everything read from LDS first, so that no read has to queue behind this step's plane writes
+        {
+            float4 pe[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pe[r] = L.pe[t][4 * q + r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                at[r] = fast_exp2(cur.sc[r] - mrun[r]) * linv[r];
+                dsc[r] = at[r] * (((pe[r].x + pe[r].y) + (pe[r].z + pe[r].w)) - Dd[r]);
+            }
+        }
+        f32x4 g0, g1, g2, g3;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            const int64_t row = (int64_t)t * Bp + row0 + i;
-            const float rg = cur[r].rg, zg = cur[r].zg, ng = cur[r].ng, hn = cur[r].hn, hprev = cur[r].hprev;
-            const float at = fast_exp2(cur[r].sc - mrun[r]) * linv[r];
-            const float4 pe = L.pe[t][i];
-            const float dsc = at * (((pe.x + pe.y) + (pe.z + pe.w)) - Dd[r]);
-            if (wq == 0 && jl == 0) s.bw_dsc[row] = dsc;
-            daw = fmaf(dsc, hnext[r], daw); dab += dsc;
-            hnext[r] = hprev;
-            const float dh = dhc[r] + at * dpool[r] + dsc * awj;
+            const float rg = cur.rg[r], zg = cur.zg[r], ng = cur.ng[r], hn = cur.hn[r], hprev = cur.hprev[r];
+            daw = fmaf(dsc[r], hnext[r], daw); dab += dsc[r];
+            const float dh = dhc[r] + at[r] * dpool[r] + dsc[r] * awj;
             const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
             const float dzp = dh * (hprev - ng) * zg * (1.0f - zg);
             const float drp = dnp * hn * rg * (1.0f - rg);
             const float ghn = dnp * rg;
-            float* grow = s.bw_g + row * 256;
-            grow[j] = drp; grow[E + j] = dzp; grow[2 * E + j] = dnp; grow[3 * E + j] = ghn;
+            g0[r] = drp; g1[r] = dzp; g2[r] = dnp; g3[r] = ghn;
             {
                 const float dv[3] = {drp, dzp, ghn};
 #pragma unroll
-                for (int g3 = 0; g3 < 3; ++g3) {
+                for (int g3i = 0; g3i < 3; ++g3i) {
                     unsigned u0, u1, u2;
-                    split3(dv[g3], u0, u1, u2);
-                    L.gp[buf][0][i * GPL + g3 * E + j] = (unsigned short)(u0 >> 16);
-                    L.gp[buf][1][i * GPL + g3 * E + j] = (unsigned short)(u1 >> 16);
-                    L.gp[buf][2][i * GPL + g3 * E + j] = (unsigned short)(u2 >> 16);
+                    split3(dv[g3i], u0, u1, u2);
+                    L.gp[buf][0][i * GPL + g3i * E + j] = (unsigned short)(u0 >> 16);
+                    L.gp[buf][1][i * GPL + g3i * E + j] = (unsigned short)(u1 >> 16);
+                    L.gp[buf][2][i * GPL + g3i * E + j] = (unsigned short)(u2 >> 16);
                 }
             }
             zs[r] = zg; dhs[r] = dh;
+        }
+        hnext = cur.hprev;
+        {                                                      // d(pre-activation) record for the weight gradients
+            float* gb = s.bw_g + ((((int64_t)t * ntile + tile) * 4) * 4 + wq) * 256 + lo4;
+            *reinterpret_cast<f32x4*>(gb) = g0; *reinterpret_cast<f32x4*>(gb + 1024) = g1;
+            *reinterpret_cast<f32x4*>(gb + 2048) = g2; *reinterpret_cast<f32x4*>(gb + 3072) = g3;
         }
         if (t >= 3) fetch(cur, t - 3);                         // this buffer's next occupant starts its trip
         if (t == 0) return;                                    // dh_{-1} is not needed
@@ -469,17 +517,35 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
 struct GruPrepBwdArgs { const float* whh[3]; u32x4* out[3]; };
 __global__ __launch_bounds__(256) void gru_prepare_bwd_kernel(GruPrepBwdArgs a) {
     const int tid = blockIdx.x * 256 + threadIdx.x;           // grid = n * 6 blocks of 256
-    const int lane = tid & 63, rest = tid >> 6, c = rest % 6, wq = (rest / 6) & 3, slot = rest / 24;
-    const int jl = lane & 15, q = lane >> 4;
-    const float* w = a.whh[slot] + (int64_t)(32 * c + 8 * q) * E + 16 * wq + jl;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = w[e * E];
-    u32x4 hi, mid, lo;
-    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, mid, lo);
-    u32x4* o = a.out[slot] + ((wq * 6 + c) * 3) * 64 + lane;
-    o[0] = hi; o[64] = mid; o[128] = lo;
+    const int slot = tid / 1536;
+    prep_gru_bwd(a.whh[slot], a.out[slot], tid - slot * 1536);
 }
+
+// ---- the learner's one-launch prepare (all-GRU network, 192-128-128-A head): block ranges
+//   [0, 18) policy W_hh forward   [18, 36) target W_hh forward   [36, 54) policy W_hh backward
+//   [54, 75) policy head forward  [75, 96) target head forward   [96, 118) policy head backward
+__global__ __launch_bounds__(256) void dqn_prepare_kernel(DqnPrepArgs a) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b < 36) {
+        const int net = b / 18, tid = (b - net * 18) * 256 + t, slot = tid / 1536;
+        prep_gru_fwd(a.whh[net][slot], a.gru_fwd[net] + (int64_t)slot * (GRU_PREP_BYTES / 16), tid - slot * 1536);
+    } else if (b < 54) {
+        const int tid = (b - 36) * 256 + t, slot = tid / 1536;
+        prep_gru_bwd(a.whh[0][slot], a.gru_bwd[slot], tid - slot * 1536);
+    } else if (b < 96) {
+        const int net = (b - 54) / 21, tid = (b - 54 - net * 21) * 256 + t;
+        prep_head_fwd(a.hw[net][0], a.hw[net][1], a.hw[net][2], a.A, a.head_fwd[net], tid);
+    } else {
+        prep_head_bwd(a.hw[0][0], a.hw[0][1], a.hw[0][2], a.A, a.head_bwd, (b - 96) * 256 + t);
+    }
+}
+int launch_dqn_prepare(const DqnPrepArgs& a, hipStream_t st) {
+    static_assert(HEAD_PREP_THREADS == 21 * 256 && HEAD_PREP_BWD_THREADS == 22 * 256, "block ranges of dqn_prepare_kernel");
+    hipLaunchKernelGGL(dqn_prepare_kernel, dim3(118), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gru_prepare_bwd(const float* const whh[3], int n, void* const out[3], hipStream_t st) {
     if (n == 0) return 0;
     GruPrepBwdArgs a;
@@ -501,15 +567,17 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
 }
 
 // ================================================== GRU weight gradients (fused, one pass per slot)
-// Block = 4 waves, `rows` k-rows of one slot, walked in slabs of 32 rows staged through LDS (float4
-// loads, next slab in flight while the current one feeds the MFMAs).  Per 4-row k-step wave w issues
-// 15 MFMAs: [dr|dz] columns 32w..32w+31 against the four H tiles and the X tile (10), dn columns
-// 128+16w.. against X (1), dn*r columns 192+16w.. against the four H tiles (4); the A fragments'
-// column sums (bias gradients) ride along as VALU adds.  LDS row = 256 G | 64 H | 16 X floats; the
-// stride 336 = 16 (mod 64) keeps the operand reads of the 4 k-rows in disjoint bank groups.
-constexpr int GW_LD = 336, GW_KT = 32;
+// Block = 4 waves, `rows` k-rows of one slot (k = step * Bp + row), walked in slabs of 32 rows = two 16-row tile
+// blocks of the lane-major records G (4 gates) and H_prev, staged through LDS TRANSPOSED ([column][k], row stride
+// 36: a record's float4 = four consecutive k of one column = one 16-byte LDS write, and the MFMA operand reads --
+// lane (jl, q) takes [column base + jl][4 ks + q] -- hit 64 distinct banks); the next slab is in flight while the
+// current one feeds the MFMAs.  Per 4-row k-step wave w issues 15 MFMAs: [dr|dz] columns 32w..32w+31 against the
+// four H tiles and the X tile (10), dn columns 128+16w.. against X (1), dn*r columns 192+16w.. against the four H
+// tiles (4); the A fragments' column sums (bias gradients) ride along as VALU adds.
+constexpr int GW_KT = 32, GW_LDT = 36;
+constexpr int GW_GT = 256 * GW_LDT, GW_HT = 64 * GW_LDT, GW_XS = GW_KT * 16, GW_BUF = GW_GT + GW_HT + GW_XS;
 __global__ __launch_bounds__(256) void gru_wgrad_kernel(GruWgradArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float gw_lds[];           // [2][GW_KT * GW_LD]
+    extern __shared__ __attribute__((aligned(16))) float gw_lds[];           // [2][GW_BUF]
     int si = 0;
     for (int k = 1; k < args.nslots; ++k)
         if ((int)blockIdx.x >= args.slot[k].blk0) si = k;
@@ -517,26 +585,46 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(GruWgradArgs args) {
     const int split = blockIdx.x - S.blk0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
     const int k0 = split * S.rows, k1 = min(k0 + S.rows, S.K), F = S.F;
-    // staging roles: G 8 float4 per lane (row tid>>6 + 4p, cols 4*(tid&63)..), H 2 float4 (row tid>>4 + 16p,
-    // cols 4*(tid&15)..), X 1 float (row tid>>3, col tid&7)
-    const int gr = tid >> 6, gc = (tid & 63) * 4, hr = tid >> 4, hc = (tid & 15) * 4, xr = tid >> 3, xc = tid & 7;
-    f32x4 rg0, rg1, rg2, rg3, rg4, rg5, rg6, rg7, rh0, rh1;
+    // staging roles: float4 number tid + 256 p of the slab's G blocks (p < 8) and H blocks (p < 2); X one float
+    const int xr = tid >> 3, xc = tid & 7;
+    f32x4 rg[8], rh[2];
     float rx;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-#define GW_LOADG(R, P) { const int k_ = kb_ + gr + 4 * (P); R = k_ < k1 ? *reinterpret_cast<const f32x4*>(S.G + (int64_t)k_ * 256 + gc) : z4; }
-#define GW_LOADH(R, P) { const int k_ = kb_ + hr + 16 * (P); R = k_ < k1 ? *reinterpret_cast<const f32x4*>(S.Hprev + (int64_t)k_ * E + hc) : z4; }
-#define GW_FETCH(KB) { const int kb_ = (KB); GW_LOADG(rg0, 0) GW_LOADG(rg1, 1) GW_LOADG(rg2, 2) GW_LOADG(rg3, 3) \
-        GW_LOADG(rg4, 4) GW_LOADG(rg5, 5) GW_LOADG(rg6, 6) GW_LOADG(rg7, 7) GW_LOADH(rh0, 0) GW_LOADH(rh1, 1) \
-        { const int k_ = kb_ + xr; rx = k_ < k1 ? S.X[(int64_t)k_ * 8 + xc] : 0.0f; } }
-#define GW_STG(R, P) *reinterpret_cast<f32x4*>(&Lb_[(gr + 4 * (P)) * GW_LD + gc]) = R;
-#define GW_STASH(BUF) { float* Lb_ = gw_lds + (BUF) * (GW_KT * GW_LD); GW_STG(rg0, 0) GW_STG(rg1, 1) GW_STG(rg2, 2) \
-        GW_STG(rg3, 3) GW_STG(rg4, 4) GW_STG(rg5, 5) GW_STG(rg6, 6) GW_STG(rg7, 7) \
-        *reinterpret_cast<f32x4*>(&Lb_[hr * GW_LD + 256 + hc]) = rh0; \
-        *reinterpret_cast<f32x4*>(&Lb_[(hr + 16) * GW_LD + 256 + hc]) = rh1; Lb_[xr * GW_LD + 320 + xc] = rx; }
+    auto fetch = [&](int kb) {                               // slab starting at k-row kb (a multiple of 32) -> registers
+        const int64_t b0 = kb >> 4;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = tid + 256 * p, blk = f >> 10;
+            rg[p] = kb + 16 * blk < k1 ? *reinterpret_cast<const f32x4*>(S.G + (b0 + blk) * 4096 + (int64_t)(f & 1023) * 4) : z4;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int f = tid + 256 * p, blk = f >> 8;
+            rh[p] = kb + 16 * blk < k1 ? *reinterpret_cast<const f32x4*>(S.Hprev + (b0 + blk) * 1024 + (int64_t)(f & 255) * 4) : z4;
+        }
+        const int k_ = kb + xr;
+        rx = k_ < k1 ? S.X[(int64_t)k_ * 8 + xc] : 0.0f;
+    };
+    auto stash = [&](int buf) {
+        float* Lb = gw_lds + buf * GW_BUF;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = tid + 256 * p, blk = f >> 10, rem = f & 1023, ln = rem & 63;
+            const int col = (rem >> 8) * 64 + ((rem >> 6) & 3) * 16 + (ln & 15);
+            *reinterpret_cast<f32x4*>(&Lb[col * GW_LDT + blk * 16 + 4 * (ln >> 4)]) = rg[p];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int f = tid + 256 * p, blk = f >> 8, rem = f & 255, ln = rem & 63;
+            const int col = (rem >> 6) * 16 + (ln & 15);
+            *reinterpret_cast<f32x4*>(&Lb[GW_GT + col * GW_LDT + blk * 16 + 4 * (ln >> 4)]) = rh[p];
+        }
+        Lb[GW_GT + GW_HT + xr * 16 + xc] = rx;
+    };
     // X tile columns 8..15 stay zero in both buffers
     for (int i = tid; i < 2 * GW_KT * 8; i += 256) {
         const int b = i / (GW_KT * 8), rr = (i >> 3) % GW_KT, cc = i & 7;
-        gw_lds[b * (GW_KT * GW_LD) + rr * GW_LD + 328 + cc] = 0.0f;
+        gw_lds[b * GW_BUF + GW_GT + GW_HT + rr * 16 + 8 + cc] = 0.0f;
     }
     f32x4 arz[2][5], an = {0, 0, 0, 0}, anr[4];
 #pragma unroll
@@ -546,19 +634,24 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(GruWgradArgs args) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) anr[t] = f32x4{0, 0, 0, 0};
     float bs0 = 0.f, bs1 = 0.f, bsn = 0.f, bsr = 0.f;
-    GW_FETCH(k0)
-    GW_STASH(0)
+    fetch(k0);
+    stash(0);
     __syncthreads();
     int buf = 0;
     for (int kb = k0; kb < k1; kb += GW_KT) {
         const bool more = kb + GW_KT < k1;
-        if (more) GW_FETCH(kb + GW_KT)
-        const float* Lb = gw_lds + buf * (GW_KT * GW_LD) + q * GW_LD + jl;
+        if (more) fetch(kb + GW_KT);
+        const float* Lb = gw_lds + buf * GW_BUF;
+        const float* ga = Lb + jl * GW_LDT + q;                  // A operands: [column][k]
+        const float* hb = Lb + GW_GT + jl * GW_LDT + q;          // H tiles:    [unit][k]
+        const float* xb = Lb + GW_GT + GW_HT + q * 16 + jl;      // X tile:     [k][feature]
 #pragma unroll
         for (int ks = 0; ks < GW_KT / 4; ++ks) {
-            const float* row = Lb + ks * 4 * GW_LD;
-            const float a0 = row[32 * w], a1 = row[32 * w + 16], a2 = row[128 + 16 * w], a3 = row[192 + 16 * w];
-            const float h0 = row[256], h1 = row[272], h2 = row[288], h3 = row[304], xv = row[320];
+            const int ko = 4 * ks;
+            const float a0 = ga[(32 * w) * GW_LDT + ko], a1 = ga[(32 * w + 16) * GW_LDT + ko];
+            const float a2 = ga[(128 + 16 * w) * GW_LDT + ko], a3 = ga[(192 + 16 * w) * GW_LDT + ko];
+            const float h0 = hb[ko], h1 = hb[16 * GW_LDT + ko], h2 = hb[32 * GW_LDT + ko], h3 = hb[48 * GW_LDT + ko];
+            const float xv = xb[ko * 16];
             arz[0][0] = mfma16(a0, h0, arz[0][0]); arz[1][0] = mfma16(a1, h0, arz[1][0]); anr[0] = mfma16(a3, h0, anr[0]);
             arz[0][1] = mfma16(a0, h1, arz[0][1]); arz[1][1] = mfma16(a1, h1, arz[1][1]); anr[1] = mfma16(a3, h1, anr[1]);
             arz[0][2] = mfma16(a0, h2, arz[0][2]); arz[1][2] = mfma16(a1, h2, arz[1][2]); anr[2] = mfma16(a3, h2, anr[2]);
@@ -566,15 +659,10 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(GruWgradArgs args) {
             arz[0][4] = mfma16(a0, xv, arz[0][4]); arz[1][4] = mfma16(a1, xv, arz[1][4]); an = mfma16(a2, xv, an);
             bs0 += a0; bs1 += a1; bsn += a2; bsr += a3;
         }
-        if (more) GW_STASH(buf ^ 1)
+        if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-#undef GW_LOADG
-#undef GW_LOADH
-#undef GW_FETCH
-#undef GW_STG
-#undef GW_STASH
     // ---- partials in the three WJob layouts: D register r of lane (jl, q) is [m = 4q + r][n = jl] ----
     float* Pih = S.wp_ih + (int64_t)split * (G3 * F + G3);
     float* Prz = S.wp_rz + (int64_t)split * (128 * E + 128);
@@ -617,7 +705,7 @@ void gru_wgrad_geometry(int64_t K, int* rows, int* nsplit) {
 
 int launch_gru_wgrad(const GruWgradArgs& a, hipStream_t st) {
     if (a.nslots == 0 || a.nblocks == 0) return 0;
-    const size_t lds = 2 * GW_KT * GW_LD * sizeof(float);     // 86 KB
+    const size_t lds = 2 * GW_BUF * sizeof(float);            // 94 KB
     static bool once = false;
     if (!once) {
         MCTSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_wgrad_kernel),
@@ -728,36 +816,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, const float* __
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const float* __restrict__ partials,
-                                                           float* __restrict__ grad, int64_t total) {
+                                                           float* __restrict__ grad, int64_t total, ReduceExtras ex) {
+    __shared__ double s_sq[4];
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    int64_t base = 0;
-    int ji = 0;
-    for (; ji < jl.njobs; ++ji) {
-        const int64_t n = (int64_t)jl.job[ji].M * jl.job[ji].N + jl.job[ji].M;
-        if (e < base + n) break;
-        base += n;
-    }
-    const WJob& J = jl.job[ji];
-    const int64_t le = e - base, mn = (int64_t)J.M * J.N, stride = mn + J.M;
-    const float* p = partials + J.part_off + le;
-    float acc = 0.0f;
-    int sp = 0;
-    for (; sp + 8 <= J.nsplit; sp += 8) {                     // eight loads in flight, summed in split order
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u) * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; sp < J.nsplit; ++sp) acc += p[(int64_t)sp * stride];
-    if (le < mn) {
-        if (J.out_w >= 0) {
-            const int64_t m = le / J.N, n = le - m * J.N;
-            grad[J.out_w + m * (int64_t)J.out_ldm + n * (int64_t)J.out_sn] = acc;
+    float written = 0.0f;
+    if (e < total) {
+        int64_t base = 0;
+        int ji = 0;
+        for (; ji < jl.njobs; ++ji) {
+            const int64_t n = (int64_t)jl.job[ji].M * jl.job[ji].N + jl.job[ji].M;
+            if (e < base + n) break;
+            base += n;
         }
-    } else if (J.out_b >= 0) {
-        grad[J.out_b + (le - mn)] = acc;
+        const WJob& J = jl.job[ji];
+        const int64_t le = e - base, mn = (int64_t)J.M * J.N, stride = mn + J.M;
+        const float* p = partials + J.part_off + le;
+        float acc = 0.0f;
+        int sp = 0;
+        for (; sp + 8 <= J.nsplit; sp += 8) {                 // eight loads in flight, summed in split order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; sp < J.nsplit; ++sp) acc += p[(int64_t)sp * stride];
+        if (le < mn) {
+            if (J.out_w >= 0) {
+                const int64_t m = le / J.N, n = le - m * J.N;
+                grad[J.out_w + m * (int64_t)J.out_ldm + n * (int64_t)J.out_sn] = acc;
+                written = acc;
+            }
+        } else if (J.out_b >= 0) {
+            grad[J.out_b + (le - mn)] = acc;
+            written = acc;
+        }
+    }
+    if (ex.sumsq_parts) {                                     // this block's share of |grad|^2, fixed order
+        double sq = (double)written * (double)written;
+        for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d, 64);
+        if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) ex.sumsq_parts[blockIdx.x] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
+    }
+    if (ex.loss_parts && blockIdx.x == 0 && threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < ex.n_loss_parts; ++i) t += ex.loss_parts[i];
+        *ex.loss_out = (float)(t * ex.loss_norm);
     }
 }
 
@@ -768,12 +873,20 @@ int launch_wgrad(const WJobList& jl, const float* ws, float* partials, hipStream
     return 0;
 }
 
-int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, hipStream_t st) {
-    if (jl.njobs == 0) return 0;
+static int64_t reduce_total(const WJobList& jl) {
     int64_t total = 0;
     for (int i = 0; i < jl.njobs; ++i) total += (int64_t)jl.job[i].M * jl.job[i].N + jl.job[i].M;
+    return total;
+}
+int wgrad_reduce_blocks(const WJobList& jl) { return jl.njobs == 0 ? 0 : (int)((reduce_total(jl) + 255) / 256); }
+
+int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, const ReduceExtras* ex, hipStream_t st) {
+    if (jl.njobs == 0) return 0;
+    const int64_t total = reduce_total(jl);
+    ReduceExtras e;
+    if (ex) e = *ex; else memset(&e, 0, sizeof(e));
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, jl, partials,
-                       grad, total);
+                       grad, total, e);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

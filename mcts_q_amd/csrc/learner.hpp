@@ -33,6 +33,12 @@ struct HeadBwdArgs {
     float* d_act[4];            // out: d(pre-activation) of hidden layer l, [Bp][H]
     float* dfeat;               // out: [Bp][192]
     const void* wprep_bwd;      // 192-128-128-A head only: transposed split-bf16 fragments (head_prepare_bwd_kernel), or NULL
+    // 192-128-128-A head only: the TD loss (td_loss_kernel's arithmetic) evaluated in this kernel's prologue for the
+    // tile's 16 rows instead of a launch of its own; td.dq is then an OUTPUT (the last layer's weight-gradient
+    // job reads it) and the tile's loss sum goes to loss_parts[tile] (summed in tile order by wgrad_reduce_kernel)
+    bool fuse_td;
+    TdArgs td;
+    double* loss_parts;
 };
 int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);
 // The head's weights as B operands of d(in) = d(out) . W (k = output unit, n = input unit), split into bf16 planes,
@@ -112,6 +118,17 @@ struct WJobList {
     int njobs, nblocks_total;
 };
 int launch_wgrad(const WJobList& jl, const float* ws, float* partials, hipStream_t st);
-int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, hipStream_t st);
+// sumsq_parts (optional): one fp64 sum of squares of the reduced gradient entries per block of this launch
+// (block order), the pieces of the global gradient norm; returns the number of blocks through *nblocks.
+// loss_parts (optional): per-tile loss sums of the fused head backward, folded in order into *loss_out * loss_norm
+struct ReduceExtras {
+    double* sumsq_parts;
+    const double* loss_parts;
+    int n_loss_parts;
+    double loss_norm;
+    float* loss_out;
+};
+int wgrad_reduce_blocks(const WJobList& jl);
+int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, const ReduceExtras* ex, hipStream_t st);
 
 }  // namespace mctsq

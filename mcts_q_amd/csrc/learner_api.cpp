@@ -11,6 +11,8 @@
 
 #include "forward.hpp"
 #include "learner.hpp"
+#include "per.hpp"
+#include "prepare_core.hpp"
 
 using namespace mctsq;
 
@@ -43,7 +45,7 @@ struct SlotPlan {                      // float offsets; which fields are used d
 
 struct TrainPlan {
     int64_t Bp;
-    int64_t feats_t, q_t, qnext, feats_p, q_p, dq, dfeat;
+    int64_t feats_t, q_t, qnext, feats_p, q_p, dq, dfeat, loss_parts;
     int64_t act[4], dact[4];
     int64_t head_prep_bwd;                               // transposed split-bf16 head fragments (-1: generic head)
     SlotPlan slot[3];
@@ -69,6 +71,7 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
     P->feats_t = c.take(forward_ws_floats(L, Bp)); P->q_t = c.take(Bp * L.A); P->qnext = c.take(Bp);
     P->feats_p = c.take(forward_ws_floats(L, Bp)); P->q_p = c.take(Bp * L.A);
     P->dq = c.take(Bp * DQ_LD); P->dfeat = c.take(Bp * FEAT);
+    P->loss_parts = c.take(2 * (Bp / TILE));                 // one fp64 loss sum per tile (fused head backward)
     for (int i = 0; i + 1 < L.n_fc; ++i) {
         P->act[i] = c.take(Bp * L.fc_out[i]);
         P->dact[i] = c.take(Bp * L.fc_out[i]);
@@ -186,13 +189,14 @@ struct JobBuilder {
 }  // namespace
 
 namespace {
-// The target forward (on s') and the policy forward (on s) are independent and each fills only part of
-// the chip at training batch sizes, so they run side by side: the target network goes to a helper
-// stream forked from / joined to the caller's stream with events (no host synchronisation; the pattern
-// is also legal under stream capture).  One helper stream and event pair per (device, caller stream),
-// created on first use and kept for the life of the process, so calls on different streams never share
-// events; calls on the SAME stream are ordered by the caller (one host thread enqueues on a stream at a time).
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+// The step is a small DAG, not a chain: the target forward (on s') runs beside the policy forward (on s), and after
+// the head backward the weight-gradient products that only need the head's deltas, and the backward of the SHORT
+// GRU windows with their weight gradients, run beside the backward of the longest window.  The second lane is a
+// helper stream forked from / joined to the caller's stream with events (no host synchronisation; the pattern is
+// also legal under stream capture).  One helper stream and event set per (device, caller stream), created on first
+// use and kept for the life of the process, so calls on different streams never share events; calls on the SAME
+// stream are ordered by the caller (one host thread enqueues on a stream at a time).
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, head = nullptr, join2 = nullptr; };
 std::mutex g_side_mu;
 std::map<std::pair<int, void*>, SideStream> g_side;
 int side_stream(hipStream_t caller, SideStream* out) {
@@ -204,11 +208,88 @@ int side_stream(hipStream_t caller, SideStream* out) {
         MCTSQ_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+        MCTSQ_HIP(hipEventCreateWithFlags(&s.head, hipEventDisableTiming));
+        MCTSQ_HIP(hipEventCreateWithFlags(&s.join2, hipEventDisableTiming));
     }
     *out = s;
     return 0;
 }
+
+bool head_is_bf16(const NetLayout& L) {
+    return L.n_fc == 3 && L.fc_in[0] == FEAT && L.fc_out[0] == 128 && L.fc_in[1] == 128 && L.fc_out[1] == 128 &&
+           L.fc_in[2] == 128 && L.A <= 16;
+}
+int n_gru_slots(const NetLayout& L) {
+    int n = 0;
+    for (int s = 0; s < 3; ++s) n += L.enc[s].kind == MCTSQ_ENC_GRU;
+    return n;
+}
+// the learner's backward fragments: [head (192-128-128-A only)] [W_hh of every GRU slot, slot order]
+int64_t prep_bwd_bytes(const NetLayout& L) {
+    return (head_is_bf16(L) ? HEAD_PREP_BWD_BYTES : 0) + n_gru_slots(L) * GRU_PREP_BYTES;
+}
+struct DqnPrep { const void* policy; const void* target; const void* bwd; };
+// priority write-back of the step's |td| (dqn_per.py:474), enqueued on the helper lane as soon as the TD errors
+// exist (behind the head backward) instead of at the end of the step: it depends on nothing later
+struct PerUpdateHook {
+    unsigned long long* tree; double* prio; int32_t* stamp; int64_t cap, head, size; const int64_t* idx;
+    double alpha; int64_t mass_cap;
+};
+
+int prepare_bwd(const NetLayout& L, const float* params, void* bwd, hipStream_t st) {
+    char* p = (char*)bwd;
+    if (head_is_bf16(L)) {
+        if (launch_head_prepare_bwd(params + L.fc_w[0], params + L.fc_w[1], params + L.fc_w[2], L.A, p, st)) return -1;
+        p += HEAD_PREP_BWD_BYTES;
+    }
+    const float* whh[3] = {nullptr, nullptr, nullptr};
+    void* wt[3] = {nullptr, nullptr, nullptr};
+    int n = 0;
+    for (int s = 0; s < 3; ++s)
+        if (L.enc[s].kind == MCTSQ_ENC_GRU) { whh[n] = params + L.enc[s].gru.whh; wt[n] = p + n * GRU_PREP_BYTES; ++n; }
+    return launch_gru_prepare_bwd(whh, n, wt, st);
+}
 }  // namespace
+
+extern "C" int64_t mctsq_dqn_prepared_bwd_bytes(const mctsq_net_desc* net) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    return prep_bwd_bytes(L);
+}
+
+extern "C" int mctsq_dqn_prepare(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
+                                 void* d_prep_policy, void* d_prep_target, void* d_prep_bwd, void* stream) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    MCTSQ_CHECK(d_params && d_target_params, "NULL device pointer");
+    MCTSQ_CHECK((d_prep_policy && d_prep_target) || prepared_bytes(L) == 0, "NULL prepared-weights pointer");
+    MCTSQ_CHECK(d_prep_bwd || prep_bwd_bytes(L) == 0, "NULL backward prepared-weights pointer");
+    MCTSQ_CHECK((((uintptr_t)d_prep_policy | (uintptr_t)d_prep_target | (uintptr_t)d_prep_bwd) & 15) == 0,
+                "prepared buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_gru_slots(L) == 3 && head_is_bf16(L)) {           // shipped default: one launch for all of it
+        DqnPrepArgs a;
+        const float* par[2] = {d_params, d_target_params};
+        void* fwd[2] = {d_prep_policy, d_prep_target};
+        for (int n = 0; n < 2; ++n) {
+            for (int s = 0; s < 3; ++s) a.whh[n][s] = par[n] + L.enc[s].gru.whh;
+            for (int l = 0; l < 3; ++l) a.hw[n][l] = par[n] + L.fc_w[l];
+            a.gru_fwd[n] = reinterpret_cast<u32x4*>(fwd[n]);
+            a.head_fwd[n] = reinterpret_cast<u32x4*>((char*)fwd[n] + 3 * GRU_PREP_BYTES);
+        }
+        a.head_bwd = reinterpret_cast<u32x4*>(d_prep_bwd);
+        for (int s = 0; s < 3; ++s)
+            a.gru_bwd[s] = reinterpret_cast<u32x4*>((char*)d_prep_bwd + HEAD_PREP_BWD_BYTES + s * GRU_PREP_BYTES);
+        a.A = L.A;
+        return launch_dqn_prepare(a, st);
+    }
+    if (prepared_bytes(L) > 0) {
+        if (prepare_impl(L, d_params, d_prep_policy, st)) return -1;
+        if (prepare_impl(L, d_target_params, d_prep_target, st)) return -1;
+    }
+    if (prep_bwd_bytes(L) > 0 && prepare_bwd(L, d_params, d_prep_bwd, st)) return -1;
+    return 0;
+}
 
 extern "C" int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
     NetLayout L;
@@ -219,26 +300,33 @@ extern "C" int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int
     return P.total * (int64_t)sizeof(float);
 }
 
-static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideStream* side, const float* d_params,
-                            const float* d_target_params, const float* d_sprice, const float* d_sprocess,
-                            const float* d_sgas, const float* d_nprice, const float* d_nprocess, const float* d_ngas,
-                            const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
-                            float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss, float* d_abs_td,
-                            float* d_qsa, float* d_target, float* ws, hipStream_t st);
+static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideStream* side, const DqnPrep* pp,
+                            const float* d_params, const float* d_target_params, const float* d_sprice,
+                            const float* d_sprocess, const float* d_sgas, const float* d_nprice,
+                            const float* d_nprocess, const float* d_ngas, const int32_t* d_act, const float* d_rew,
+                            const float* d_done, const float* d_isw, float gamma, float loss_scale, int64_t B,
+                            float* d_grad, float* d_loss, float* d_abs_td, float* d_qsa, float* d_target,
+                            double* d_sumsq_parts, const PerUpdateHook* upd, float* ws, hipStream_t st);
 
-extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
-                              const float* d_sprice, const float* d_sprocess, const float* d_sgas,
-                              const float* d_nprice, const float* d_nprocess, const float* d_ngas,
-                              const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
-                              float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss,
-                              float* d_abs_td, float* d_qsa, float* d_target, void* d_ws, int64_t ws_bytes,
-                              void* stream) {
+static int dqn_grad_entry(const mctsq_net_desc* net, const DqnPrep* pp, const float* d_params,
+                          const float* d_target_params, const float* d_sprice, const float* d_sprocess,
+                          const float* d_sgas, const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                          const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
+                          float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss, float* d_abs_td,
+                          float* d_qsa, float* d_target, double* d_sumsq_parts, void* d_ws, int64_t ws_bytes,
+                          void* stream, const PerUpdateHook* upd = nullptr) {
     NetLayout L;
     if (build_layout(net, &L)) return -1;
     MCTSQ_CHECK(B >= 1, "batch must be >= 1");
     MCTSQ_CHECK(d_params && d_target_params && d_sprice && d_sprocess && d_sgas && d_nprice && d_nprocess &&
                     d_ngas && d_act && d_rew && d_done && d_isw && d_grad && d_loss && d_abs_td,
                 "NULL device pointer");
+    if (pp) {
+        MCTSQ_CHECK((pp->policy && pp->target) || prepared_bytes(L) == 0, "NULL prepared-weights pointer");
+        MCTSQ_CHECK(pp->bwd || prep_bwd_bytes(L) == 0, "NULL backward prepared-weights pointer");
+        MCTSQ_CHECK((((uintptr_t)pp->policy | (uintptr_t)pp->target | (uintptr_t)pp->bwd) & 15) == 0,
+                    "prepared buffers must be 16-byte aligned");
+    }
     TrainPlan P;
     if (make_plan(L, B, &P)) return -1;
     MCTSQ_CHECK(d_ws && ws_bytes >= P.total * (int64_t)sizeof(float), "workspace too small: %lld < %lld bytes",
@@ -249,35 +337,87 @@ extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, 
     if (side_stream(st, &side)) return -1;
     MCTSQ_HIP(hipEventRecord(side.fork, st));
     MCTSQ_HIP(hipStreamWaitEvent(side.st, side.fork, 0));
-    const int rc = dqn_grad_enqueue(L, P, &side, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice,
+    const int rc = dqn_grad_enqueue(L, P, &side, pp, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice,
                                     d_nprocess, d_ngas, d_act, d_rew, d_done, d_isw, gamma, loss_scale, B, d_grad,
-                                    d_loss, d_abs_td, d_qsa, d_target, (float*)d_ws, st);
+                                    d_loss, d_abs_td, d_qsa, d_target, d_sumsq_parts, upd, (float*)d_ws, st);
     if (rc != 0) {                     // whatever was enqueued on the helper stream is joined back before returning
-        hipEventRecord(side.join, side.st);
-        hipStreamWaitEvent(st, side.join, 0);
+        (void)hipEventRecord(side.join2, side.st);
+        (void)hipStreamWaitEvent(st, side.join2, 0);
     }
     return rc;
 }
 
-static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideStream* side, const float* d_params,
-                            const float* d_target_params, const float* d_sprice, const float* d_sprocess,
-                            const float* d_sgas, const float* d_nprice, const float* d_nprocess, const float* d_ngas,
-                            const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
-                            float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss, float* d_abs_td,
-                            float* d_qsa, float* d_target, float* ws, hipStream_t st) {
+extern "C" int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
+                              const float* d_sprice, const float* d_sprocess, const float* d_sgas,
+                              const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                              const int32_t* d_act, const float* d_rew, const float* d_done, const float* d_isw,
+                              float gamma, float loss_scale, int64_t B, float* d_grad, float* d_loss,
+                              float* d_abs_td, float* d_qsa, float* d_target, void* d_ws, int64_t ws_bytes,
+                              void* stream) {
+    return dqn_grad_entry(net, nullptr, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice, d_nprocess,
+                          d_ngas, d_act, d_rew, d_done, d_isw, gamma, loss_scale, B, d_grad, d_loss, d_abs_td, d_qsa,
+                          d_target, nullptr, d_ws, ws_bytes, stream);
+}
+
+extern "C" int64_t mctsq_dqn_grad_sumsq_parts(const mctsq_net_desc* net) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    // one part per 256 reduced entries, rounded up per reduction launch (<= 4 launches): an upper bound
+    return (L.total + 255) / 256 + 8 * 160;
+}
+
+extern "C" int mctsq_dqn_grad_prepared(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
+                                       const void* d_prep_policy, const void* d_prep_target, const void* d_prep_bwd,
+                                       const float* d_sprice, const float* d_sprocess, const float* d_sgas,
+                                       const float* d_nprice, const float* d_nprocess, const float* d_ngas,
+                                       const int32_t* d_act, const float* d_rew, const float* d_done,
+                                       const float* d_isw, float gamma, float loss_scale, int64_t B, float* d_grad,
+                                       float* d_loss, float* d_abs_td, float* d_qsa, float* d_target,
+                                       double* d_sumsq_parts, int64_t* n_sumsq_parts, void* d_ws, int64_t ws_bytes,
+                                       void* stream) {
+    DqnPrep pp{d_prep_policy, d_prep_target, d_prep_bwd};
+    const int rc = dqn_grad_entry(net, &pp, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice, d_nprocess,
+                                  d_ngas, d_act, d_rew, d_done, d_isw, gamma, loss_scale, B, d_grad, d_loss, d_abs_td,
+                                  d_qsa, d_target, d_sumsq_parts, d_ws, ws_bytes, stream);
+    if (rc < 0) return rc;
+    if (n_sumsq_parts) *n_sumsq_parts = rc;
+    return 0;
+}
+
+// returns the number of gradient-norm parts written (>= 0) or < 0 on error
+static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideStream* side, const DqnPrep* pp,
+                            const float* d_params, const float* d_target_params, const float* d_sprice,
+                            const float* d_sprocess, const float* d_sgas, const float* d_nprice,
+                            const float* d_nprocess, const float* d_ngas, const int32_t* d_act, const float* d_rew,
+                            const float* d_done, const float* d_isw, float gamma, float loss_scale, int64_t B,
+                            float* d_grad, float* d_loss, float* d_abs_td, float* d_qsa, float* d_target,
+                            double* d_sumsq_parts, const PerUpdateHook* upd, float* ws, hipStream_t st) {
     const int64_t Bp = P.Bp;
+    const bool head_bf16 = P.head_prep_bwd >= 0;
+    // backward fragments: the caller's (prepared once per parameter change) or split here into the workspace
+    const char* bwd = pp ? (const char*)pp->bwd : nullptr;
+    const void* head_bwd_prep = nullptr;
+    const void* gru_bwd_prep[3] = {nullptr, nullptr, nullptr};
+    if (pp) {
+        if (head_bf16) { head_bwd_prep = bwd; bwd += HEAD_PREP_BWD_BYTES; }
+        for (int s = 0, n = 0; s < 3; ++s)
+            if (L.enc[s].kind == MCTSQ_ENC_GRU) gru_bwd_prep[s] = bwd + (n++) * GRU_PREP_BYTES;
+    } else {
+        if (head_bf16) head_bwd_prep = ws + P.head_prep_bwd;
+        for (int s = 0; s < 3; ++s)
+            if (L.enc[s].kind == MCTSQ_ENC_GRU) gru_bwd_prep[s] = ws + P.slot[s].wt;
+    }
 
     // 1. target network on s' -> max_a' Q (dqn_per.py:460-463), on the helper stream (forked by the caller)
     {
         // the flat gradient's alignment pads must read zero; nothing touches it before the ordered reduction (step 7,
         // behind the join), so the fill rides on the helper stream instead of the critical path
         MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
-        // ... and so does the split of the head weights the backward pass multiplies by
-        if (P.head_prep_bwd >= 0 &&
-            launch_head_prepare_bwd(d_params + L.fc_w[0], d_params + L.fc_w[1], d_params + L.fc_w[2], L.A,
-                                    ws + P.head_prep_bwd, side->st))
-            return -1;
-        {                                                    // ... and of W_hh for the BPTT product
+        if (!pp) {                                           // ... and so do the splits the backward pass multiplies by
+            if (head_bf16 &&
+                launch_head_prepare_bwd(d_params + L.fc_w[0], d_params + L.fc_w[1], d_params + L.fc_w[2], L.A,
+                                        ws + P.head_prep_bwd, side->st))
+                return -1;
             const float* whh[3] = {nullptr, nullptr, nullptr};
             void* wt[3] = {nullptr, nullptr, nullptr};
             int n = 0;
@@ -287,7 +427,8 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         }
         const float* x[3] = {d_nprice, d_nprocess, d_ngas};
         HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
-        if (forward_impl(L, d_target_params, nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr, side->st, nullptr))
+        if (forward_impl(L, d_target_params, pp ? pp->target : nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr,
+                         side->st, nullptr))
             return -1;
         MCTSQ_HIP(hipEventRecord(side->join, side->st));
     }
@@ -323,19 +464,20 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     const float* xs[3] = {d_sprice, d_sprocess, d_sgas};
     {
         HeadOut out{ws + P.q_p, nullptr, nullptr, nullptr};
-        if (forward_impl(L, d_params, nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr)) return -1;
+        if (forward_impl(L, d_params, pp ? pp->policy : nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr))
+            return -1;
     }
-    // 3. TD target, IS-weighted MSE, dLoss/dQ, new priorities (dqn_per.py:464-467, 474)
+    // 3. TD target, IS-weighted MSE, dLoss/dQ, new priorities (dqn_per.py:464-467, 474): evaluated in the prologue
+    //    of the split-bf16 head backward (one launch fewer), or by its own kernel for other head shapes
     MCTSQ_HIP(hipStreamWaitEvent(st, side->join, 0));
-    {
-        TdArgs t;
-        memset(&t, 0, sizeof(t));
-        t.q = ws + P.q_p; t.qnext = ws + P.qnext; t.act = d_act; t.rew = d_rew; t.done = d_done; t.isw = d_isw;
-        t.gamma = gamma; t.grad_scale = loss_scale * 2.0f / (float)B; t.B = B; t.Bp = Bp; t.A = L.A;
-        t.loss_norm = (double)loss_scale / (double)B;
-        t.dq = ws + P.dq; t.loss = d_loss; t.abs_td = d_abs_td; t.qsa = d_qsa; t.target = d_target;
-        if (launch_td_loss(t, st)) return -1;
-    }
+    TdArgs td;
+    memset(&td, 0, sizeof(td));
+    td.q = ws + P.q_p; td.qnext = ws + P.qnext; td.act = d_act; td.rew = d_rew; td.done = d_done; td.isw = d_isw;
+    td.gamma = gamma; td.grad_scale = loss_scale * 2.0f / (float)B; td.B = B; td.Bp = Bp; td.A = L.A;
+    td.loss_norm = (double)loss_scale / (double)B;
+    td.dq = ws + P.dq; td.loss = d_loss; td.abs_td = d_abs_td; td.qsa = d_qsa; td.target = d_target;
+    double* loss_parts = reinterpret_cast<double*>(ws + P.loss_parts);
+    if (!head_bf16 && launch_td_loss(td, st)) return -1;
     // 4. head backward
     {
         HeadBwdArgs h;
@@ -343,10 +485,26 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         h.n_fc = L.n_fc; h.act = L.act; h.Bp = Bp; h.dq = ws + P.dq; h.dfeat = ws + P.dfeat;
         for (int i = 0; i < L.n_fc; ++i) { h.w[i] = d_params + L.fc_w[i]; h.in[i] = L.fc_in[i]; h.out[i] = L.fc_out[i]; }
         for (int i = 0; i + 1 < L.n_fc; ++i) { h.sv_act[i] = ws + P.act[i]; h.d_act[i] = ws + P.dact[i]; }
-        h.wprep_bwd = P.head_prep_bwd >= 0 ? ws + P.head_prep_bwd : nullptr;
+        h.wprep_bwd = head_bwd_prep;
+        h.fuse_td = head_bf16; h.td = td; h.loss_parts = loss_parts;
         if (launch_head_bwd(h, st)) return -1;
     }
-    // 5. encoder backward (deltas)
+    MCTSQ_HIP(hipEventRecord(side->head, st));
+    MCTSQ_HIP(hipStreamWaitEvent(side->st, side->head, 0));
+    if (upd && launch_per_update(upd->tree, upd->prio, upd->stamp, upd->cap, upd->head, upd->size, upd->idx, d_abs_td, B,
+                                 upd->alpha, upd->mass_cap, side->st))
+        return -1;
+
+    // 5./6. encoder backward (deltas) and weight gradients (every tensor is one or a few K-contractions), on two
+    // lanes: `jbA` holds the products that need only the head's deltas, `jbB` those behind the encoder backward
+    JobBuilder jbA(ws), jbB(ws);
+    GruWgradArgs gwMain, gwSide;
+    memset(&gwMain, 0, sizeof(gwMain));
+    memset(&gwSide, 0, sizeof(gwSide));
+    // the longest GRU window stays on the caller's stream, the others go to the helper stream
+    int long_slot = -1;
+    for (int s = 0; s < 3; ++s)
+        if (L.enc[s].kind == MCTSQ_ENC_GRU && (long_slot < 0 || L.enc[s].S > L.enc[long_slot].S)) long_slot = s;
     {
         ConvFwdArgs ca;
         fill_conv_args(ca, L, d_params, nullptr, xs, B, Bp, ws + P.feats_p, sv);
@@ -357,13 +515,19 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         if (launch_conv_bwd(cb, st)) return -1;
         GruFwdArgs ga;
         fill_gru_args(ga, L, d_params, nullptr, xs, B, Bp, ws + P.feats_p, sv);
-        GruBwdArgs gb;
-        memset(&gb, 0, sizeof(gb));
-        gb.nslots = ga.nslots; gb.Bp = Bp; gb.dfeat = ws + P.dfeat;
-        for (int i = 0; i < ga.nslots; ++i) gb.slot[i] = ga.slot[i];
-        for (int s = 0, i = 0; s < 3; ++s)
-            if (L.enc[s].kind == MCTSQ_ENC_GRU) gb.slot[i++].wprep_t = ws + P.slot[s].wt;
-        if (launch_gru_bwd(gb, st)) return -1;
+        GruBwdArgs gbMain, gbSide;
+        memset(&gbMain, 0, sizeof(gbMain));
+        memset(&gbSide, 0, sizeof(gbSide));
+        gbMain.Bp = gbSide.Bp = Bp; gbMain.dfeat = gbSide.dfeat = ws + P.dfeat;
+        for (int s = 0, i = 0; s < 3; ++s) {
+            if (L.enc[s].kind != MCTSQ_ENC_GRU) continue;
+            GruBwdArgs& gb = s == long_slot ? gbMain : gbSide;
+            gb.slot[gb.nslots] = ga.slot[i++];
+            gb.slot[gb.nslots].wprep_t = gru_bwd_prep[s];
+            ++gb.nslots;
+        }
+        if (launch_gru_bwd(gbSide, side->st)) return -1;
+        if (launch_gru_bwd(gbMain, st)) return -1;
         MlpArgs ma;
         if (fill_mlp_args(ma, L, d_params, xs, B, Bp, ws + P.feats_p, sv)) {
             ma.dfeat = ws + P.dfeat;
@@ -386,10 +550,21 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             if (launch_tf_bwd(tb, st)) return -1;
         }
     }
-    // 6. weight gradients: every tensor is one (or a few) K-contractions
-    JobBuilder jb(ws);
-    GruWgradArgs gw;
-    memset(&gw, 0, sizeof(gw));
+    int64_t part_pos = 0;                                    // the two job lists share one partial buffer
+    auto addA = [&](const float* A, int64_t lda, int a_col0, const float* Bm, int64_t ldb, int b_col0, int M, int N,
+                    int64_t K, int64_t out_w, int64_t out_ldm, int64_t out_sn, int64_t out_b) {
+        jbA.part_pos = part_pos;
+        const int rc = jbA.add(A, lda, a_col0, Bm, ldb, b_col0, M, N, K, out_w, out_ldm, out_sn, out_b);
+        part_pos = jbA.part_pos;
+        return rc;
+    };
+    auto addB = [&](const float* A, int64_t lda, int a_col0, const float* Bm, int64_t ldb, int b_col0, int M, int N,
+                    int64_t K, int64_t out_w, int64_t out_ldm, int64_t out_sn, int64_t out_b) {
+        jbB.part_pos = part_pos;
+        const int rc = jbB.add(A, lda, a_col0, Bm, ldb, b_col0, M, N, K, out_w, out_ldm, out_sn, out_b);
+        part_pos = jbB.part_pos;
+        return rc;
+    };
     for (int s = 0; s < 3; ++s) {
         const EncOff& e = L.enc[s];
         const SlotPlan& g = P.slot[s];
@@ -401,57 +576,60 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1} -- one fused pass (gru_wgrad_kernel),
             // reduced here in block order
             {
+                GruWgradArgs& gw = s == long_slot ? gwMain : gwSide;
                 GruWgradSlot& w = gw.slot[gw.nslots++];
                 w.G = G; w.Hprev = Hprev; w.X = ws + g.x; w.K = (int)K; w.F = e.F; w.rows = g.gw_rows;
                 w.nsplit = g.gw_nsplit; w.blk0 = gw.nblocks;
                 w.wp_ih = ws + g.wp_ih; w.wp_rz = ws + g.wp_rz; w.wp_n = ws + g.wp_n;
                 gw.nblocks += g.gw_nsplit;
             }
-            if (jb.add_external(g.wp_ih - P.partials, G3, e.F, g.gw_nsplit, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
-            if (jb.add_external(g.wp_rz - P.partials, 2 * E, E, g.gw_nsplit, e.gru.whh, E, 1, e.gru.bhh)) return -1;
-            if (jb.add_external(g.wp_n - P.partials, E, E, g.gw_nsplit, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E))
+            if (jbB.add_external(g.wp_ih - P.partials, G3, e.F, g.gw_nsplit, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
+            if (jbB.add_external(g.wp_rz - P.partials, 2 * E, E, g.gw_nsplit, e.gru.whh, E, 1, e.gru.bhh)) return -1;
+            if (jbB.add_external(g.wp_n - P.partials, E, E, g.gw_nsplit, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E))
                 return -1;
             // attention score Linear(64,1): d(score) x h_t, per-tile partials written by gru_bwd_kernel
-            if (jb.add_external(g.wp_aw - P.partials, 1, E, (int)(Bp / TILE), e.gru.aw, E, 1, e.gru.ab)) return -1;
+            if (jbB.add_external(g.wp_aw - P.partials, 1, E, (int)(Bp / TILE), e.gru.aw, E, 1, e.gru.ab)) return -1;
             // LayerNorm weight / bias: column sums over the batch
-            if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1;
-            if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
+            // (dfeat * xhat is written by this slot's backward: a short window's runs on the helper stream, ahead of jbA)
+            if (s == long_slot) { if (addB(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1; }
+            else if (addA(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1;
+            if (addA(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
         } else if (e.kind == MCTSQ_ENC_CONV) {
             // conv weights [out][in][3]: one contraction per tap against the time-shifted input
             // (zero blocks at both ends of the saved images implement the padding)
             for (int tap = 0; tap < 3; ++tap) {
-                if (jb.add(ws + g.c_d2, E, 0, ws + g.c_h1 + (int64_t)tap * Bp * E, E, 0, E, E, K, e.conv.w2 + tap, 3 * E,
-                           3, tap == 0 ? e.conv.b2 : -1)) return -1;
-                if (jb.add(ws + g.c_d1, E, 0, ws + g.x + (int64_t)tap * Bp * 8, 8, 0, E, e.F, K, e.conv.w1 + tap,
-                           3 * e.F, 3, tap == 0 ? e.conv.b1 : -1)) return -1;
+                if (addB(ws + g.c_d2, E, 0, ws + g.c_h1 + (int64_t)tap * Bp * E, E, 0, E, E, K, e.conv.w2 + tap, 3 * E,
+                         3, tap == 0 ? e.conv.b2 : -1)) return -1;
+                if (addB(ws + g.c_d1, E, 0, ws + g.x + (int64_t)tap * Bp * 8, 8, 0, E, e.F, K, e.conv.w1 + tap,
+                         3 * e.F, 3, tap == 0 ? e.conv.b1 : -1)) return -1;
             }
-            if (jb.add(ws + g.dsc, 1, 0, ws + g.c_h2, E, 0, 1, E, K, e.conv.aw, E, 1, e.conv.ab)) return -1;
-            if (jb.add(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnw)) return -1;
-            if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnb)) return -1;
+            if (addB(ws + g.dsc, 1, 0, ws + g.c_h2, E, 0, 1, E, K, e.conv.aw, E, 1, e.conv.ab)) return -1;
+            if (addB(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnw)) return -1;
+            if (addA(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.conv.lnb)) return -1;
         } else if (e.kind == MCTSQ_ENC_TRANSFORMER) {
             const int64_t T = g.T;
             const TfOff& o = e.tfm;
             for (int l = 0; l < 2; ++l) {
                 const TfLayerOff& t = o.layer[l];
                 const float* hin = l == 0 ? ws + g.t_e0 : ws + g.t_hout[0];
-                if (jb.add(ws + g.t_dqkv[l], G3, 0, hin, E, 0, G3, E, T, t.inw, E, 1, t.inb)) return -1;
-                if (jb.add(ws + g.t_dx1[l], E, 0, ws + g.t_ctx[l], E, 0, E, E, T, t.ow, E, 1, t.ob)) return -1;
-                if (jb.add_external(g.t_wp1[l] - P.partials, 2048, E, g.ntb, t.l1w, E, 1, t.l1b)) return -1;
-                if (jb.add_external(g.t_wp2[l] - P.partials, E, 2048, g.ntb, t.l2w, 2048, 1, -1)) return -1;
-                if (jb.add(ws + g.t_dx2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.l2b)) return -1;
-                if (jb.add(ws + g.t_p1[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n1w)) return -1;
-                if (jb.add(ws + g.t_dy1[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n1b)) return -1;
-                if (jb.add(ws + g.t_p2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n2w)) return -1;
-                if (jb.add(ws + g.t_dy2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n2b)) return -1;
+                if (addB(ws + g.t_dqkv[l], G3, 0, hin, E, 0, G3, E, T, t.inw, E, 1, t.inb)) return -1;
+                if (addB(ws + g.t_dx1[l], E, 0, ws + g.t_ctx[l], E, 0, E, E, T, t.ow, E, 1, t.ob)) return -1;
+                if (jbB.add_external(g.t_wp1[l] - P.partials, 2048, E, g.ntb, t.l1w, E, 1, t.l1b)) return -1;
+                if (jbB.add_external(g.t_wp2[l] - P.partials, E, 2048, g.ntb, t.l2w, 2048, 1, -1)) return -1;
+                if (addB(ws + g.t_dx2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.l2b)) return -1;
+                if (addB(ws + g.t_p1[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n1w)) return -1;
+                if (addB(ws + g.t_dy1[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n1b)) return -1;
+                if (addB(ws + g.t_p2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n2w)) return -1;
+                if (addB(ws + g.t_dy2[l], E, 0, nullptr, 0, 0, E, 0, T, -1, 0, 0, t.n2b)) return -1;
             }
             // embedding Linear(F,64) and the positional table rows 0..S-1 (sum over samples)
-            if (jb.add(ws + g.t_dh0, E, 0, ws + g.t_xe, 8, 0, E, e.F, T, o.ew, e.F, 1, o.eb)) return -1;
-            if (jb.add(ws + g.t_dh0, (int64_t)e.S * E, 0, nullptr, 0, 0, e.S * E, 0, Bp, -1, 0, 0, o.pos)) return -1;
-            if (jb.add(ws + g.t_pfin, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, o.lnw)) return -1;
-            if (jb.add(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, o.lnb)) return -1;
+            if (addB(ws + g.t_dh0, E, 0, ws + g.t_xe, 8, 0, E, e.F, T, o.ew, e.F, 1, o.eb)) return -1;
+            if (addB(ws + g.t_dh0, (int64_t)e.S * E, 0, nullptr, 0, 0, e.S * E, 0, Bp, -1, 0, 0, o.pos)) return -1;
+            if (addB(ws + g.t_pfin, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, o.lnw)) return -1;
+            if (addA(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, o.lnb)) return -1;
         } else {    // mlp
-            if (jb.add(ws + g.m_d0, E, 0, ws + g.m_x, 16, 0, E, 3 * e.F, Bp, e.mlp.w0, 3 * e.F, 1, e.mlp.b0)) return -1;
-            if (jb.add(ws + g.m_d1, E, 0, ws + g.m_m0, E, 0, E, E, Bp, e.mlp.w1, E, 1, e.mlp.b1)) return -1;
+            if (addB(ws + g.m_d0, E, 0, ws + g.m_x, 16, 0, E, 3 * e.F, Bp, e.mlp.w0, 3 * e.F, 1, e.mlp.b0)) return -1;
+            if (addB(ws + g.m_d1, E, 0, ws + g.m_m0, E, 0, E, E, Bp, e.mlp.w1, E, 1, e.mlp.b1)) return -1;
         }
     }
     for (int i = 0; i < L.n_fc; ++i) {
@@ -459,14 +637,137 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         const float* delta = last ? ws + P.dq : ws + P.dact[i];
         const int64_t ldd = last ? DQ_LD : L.fc_out[i];
         const float* in = i == 0 ? ws + P.feats_p : ws + P.act[i - 1];
-        if (jb.add(delta, ldd, 0, in, L.fc_in[i], 0, L.fc_out[i], L.fc_in[i], Bp, L.fc_w[i], L.fc_in[i], 1, L.fc_b[i]))
+        if (addA(delta, ldd, 0, in, L.fc_in[i], 0, L.fc_out[i], L.fc_in[i], Bp, L.fc_w[i], L.fc_in[i], 1, L.fc_b[i]))
             return -1;
     }
-    MCTSQ_CHECK(jb.part_pos <= P.partial_floats, "internal: partial buffer plan mismatch");
-    if (launch_gru_wgrad(gw, st)) return -1;
-    for (int i = 0; i < jb.nlists; ++i)
-        if (launch_wgrad(jb.lists[i], ws, ws + P.partials, st)) return -1;
-    for (int i = 0; i < jb.nlists; ++i)
-        if (launch_wgrad_reduce(jb.lists[i], ws + P.partials, d_grad, st)) return -1;
+    MCTSQ_CHECK(part_pos <= P.partial_floats, "internal: partial buffer plan mismatch");
+    // helper stream: the head's products, then the short windows' weight gradients (their backward is already queued)
+    for (int i = 0; i < jbA.nlists; ++i)
+        if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st)) return -1;
+    if (launch_gru_wgrad(gwSide, side->st)) return -1;
+    MCTSQ_HIP(hipEventRecord(side->join2, side->st));
+    // caller's stream: the long window's weight gradients and everything else behind the encoder backward
+    if (launch_gru_wgrad(gwMain, st)) return -1;
+    for (int i = 0; i < jbB.nlists; ++i)
+        if (launch_wgrad(jbB.lists[i], ws, ws + P.partials, st)) return -1;
+    MCTSQ_HIP(hipStreamWaitEvent(st, side->join2, 0));
+    // 7. ordered reduction of all partials into the flat gradient (+ the pieces of its norm, + the loss): the two
+    // lanes' job lists are reduced by the same launches (40 jobs each)
+    WJobList rl;
+    memset(&rl, 0, sizeof(rl));
+    int nparts = 0;
+    bool first = true;
+    auto flush = [&]() {
+        if (rl.njobs == 0) return 0;
+        ReduceExtras ex;
+        memset(&ex, 0, sizeof(ex));
+        if (d_sumsq_parts) ex.sumsq_parts = d_sumsq_parts + nparts;
+        if (first && head_bf16) { ex.loss_parts = loss_parts; ex.n_loss_parts = (int)(Bp / TILE); ex.loss_norm = td.loss_norm; ex.loss_out = d_loss; }
+        if (launch_wgrad_reduce(rl, ws + P.partials, d_grad, &ex, st)) return -1;
+        nparts += wgrad_reduce_blocks(rl);
+        first = false;
+        rl.njobs = 0;
+        return 0;
+    };
+    JobBuilder* both[2] = {&jbA, &jbB};
+    for (int b = 0; b < 2; ++b)
+        for (int i = 0; i < both[b]->nlists; ++i)
+            for (int k = 0; k < both[b]->lists[i].njobs; ++k) {
+                rl.job[rl.njobs++] = both[b]->lists[i].job[k];
+                if (rl.njobs == MAX_WJOBS && flush()) return -1;
+            }
+    if (flush()) return -1;
+    return d_sumsq_parts ? nparts : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// DQNModel.update() (dqn_per.py:401-476) as ONE call: sample -> batch assembly -> gradient -> clip / Adam / Polyak
+// -> weight fragments for the next step -> priority write-back.  Same kernels and results as the separate entry
+// points called in that order; what it saves is host time (one binding call and no per-step buffer management
+// instead of five calls), which at the training batch size is what bounds the step otherwise.
+namespace {
+struct StepPlan {
+    int64_t idx, phys, w, abs_td, sprice, sprocess, sgas, nprice, nprocess, ngas, act, rew, done, sumsq, grad_ws;
+    int64_t total;                                           // bytes
+};
+int64_t take(int64_t& pos, int64_t bytes) {
+    const int64_t at = pos;
+    pos = (pos + bytes + 255) & ~int64_t(255);
+    return at;
+}
+int make_step_plan(const mctsq_net_desc* net, const NetLayout& L, int64_t B, StepPlan* S) {
+    int64_t pos = 0;
+    S->idx = take(pos, B * 8); S->phys = take(pos, B * 8); S->w = take(pos, B * 4); S->abs_td = take(pos, B * 4);
+    S->sprice = take(pos, B * L.enc[0].S * L.enc[0].Fd * 4); S->sprocess = take(pos, B * L.enc[1].S * L.enc[1].Fd * 4);
+    S->sgas = take(pos, B * L.enc[2].S * L.enc[2].Fd * 4);
+    S->nprice = take(pos, B * L.enc[0].S * L.enc[0].Fd * 4); S->nprocess = take(pos, B * L.enc[1].S * L.enc[1].Fd * 4);
+    S->ngas = take(pos, B * L.enc[2].S * L.enc[2].Fd * 4);
+    S->act = take(pos, B * 4); S->rew = take(pos, B * 4); S->done = take(pos, B * 4);
+    const int64_t np = mctsq_dqn_grad_sumsq_parts(net);
+    if (np < 0) return -1;
+    S->sumsq = take(pos, np * 8);
+    const int64_t gw = mctsq_dqn_grad_workspace_bytes(net, B);
+    if (gw < 0) return -1;
+    S->grad_ws = take(pos, gw);
+    S->total = pos;
+    return 0;
+}
+}  // namespace
+
+extern "C" int64_t mctsq_per_dqn_step_workspace_bytes(const mctsq_net_desc* net, int64_t B) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    if (B < 1) { set_error("batch must be >= 1"); return -1; }
+    StepPlan S;
+    if (make_step_plan(net, L, B, &S)) return -1;
+    return S.total;
+}
+
+extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_args* a, void* stream) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    MCTSQ_CHECK(a != nullptr, "step arguments are NULL");
+    MCTSQ_CHECK(a->B >= 1, "batch must be >= 1");
+    MCTSQ_CHECK(L.enc[0].S == 25 && L.enc[0].Fd == 1 && L.enc[1].S == 10 && L.enc[1].Fd == 6 && L.enc[2].S == 3 &&
+                    L.enc[2].Fd == 2, "the replay ring stores 25x1 / 10x6 / 3x2 windows (MCTSQ_STATE_ROW)");
+    MCTSQ_CHECK(a->d_u && a->d_ws && a->d_loss && a->d_grad && a->d_m && a->d_v && a->d_params && a->d_target_params,
+                "NULL device pointer");
+    StepPlan S;
+    if (make_step_plan(net, L, a->B, &S)) return -1;
+    MCTSQ_CHECK(a->ws_bytes >= S.total, "workspace too small: %lld < %lld bytes", (long long)a->ws_bytes,
+                (long long)S.total);
+    MCTSQ_CHECK(((uintptr_t)a->d_ws & 255) == 0, "workspace must be 256-byte aligned");
+    char* ws = (char*)a->d_ws;
+    int64_t* d_idx = (int64_t*)(ws + S.idx); int64_t* d_phys = (int64_t*)(ws + S.phys);
+    float* d_w = (float*)(ws + S.w); float* d_abs_td = (float*)(ws + S.abs_td);
+    float* sp = (float*)(ws + S.sprice); float* sc = (float*)(ws + S.sprocess); float* sg = (float*)(ws + S.sgas);
+    float* np_ = (float*)(ws + S.nprice); float* nc = (float*)(ws + S.nprocess); float* ng = (float*)(ws + S.ngas);
+    int32_t* act = (int32_t*)(ws + S.act); float* rew = (float*)(ws + S.rew); float* done = (float*)(ws + S.done);
+    double* sumsq = (double*)(ws + S.sumsq);
+    // sample + IS weights + batch assembly (dqn_per.py:412-452)
+    int rc = mctsq_per_sample_batch(a->d_tree, a->d_prio, a->capacity, a->head, a->size, a->d_u, a->B, a->alpha, a->beta,
+                                    a->mass_capacity, d_idx, d_phys, d_w, a->d_wmax, a->d_states, a->d_next_states,
+                                    a->d_actions, a->d_rewards, a->d_dones, sp, sc, sg, np_, nc, ng, act, rew, done,
+                                    a->d_per_ws, a->per_ws_bytes, stream);
+    if (rc) return rc;
+    // loss, backward (:455-470); the priority write-back (:474) rides on the helper lane behind the TD errors
+    MCTSQ_CHECK(a->d_tree && a->d_prio && a->d_stamp, "NULL device pointer");
+    MCTSQ_CHECK(a->B < ((int64_t)1 << 31), "update batch too large");
+    PerUpdateHook upd{(unsigned long long*)a->d_tree, a->d_prio, a->d_stamp, a->capacity, a->head, a->size, d_idx,
+                      a->alpha, a->mass_capacity};
+    DqnPrep pp{a->d_prep_policy, a->d_prep_target, a->d_prep_bwd};
+    rc = dqn_grad_entry(net, &pp, a->d_params, a->d_target_params, sp, sc, sg, np_, nc, ng, act, rew, done, d_w,
+                        (float)a->gamma, 1.0f, a->B, a->d_grad, a->d_loss, d_abs_td, nullptr, nullptr, sumsq,
+                        ws + S.grad_ws, S.total - S.grad_ws, stream, &upd);
+    if (rc < 0) return rc;
+    const int64_t nparts = rc;
+    // clip, Adam (:471-472) and, when tau >= 0, the target sync of mctsq_config_mcts_per.py:181 (dqn_per.py:510-516)
+    rc = mctsq_clip_adam_polyak_ex(a->d_params, a->d_grad, a->d_m, a->d_v, a->d_target_params, L.total, a->adam_step,
+                                   a->lr, a->beta1, a->beta2, a->eps, a->max_norm, a->tau, a->d_gnorm, sumsq, nparts,
+                                   nullptr, 0, stream);
+    if (rc) return rc;
+    rc = mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd,
+                           stream);
+    if (rc) return rc;
     return 0;
 }

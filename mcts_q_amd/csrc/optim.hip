@@ -27,7 +27,8 @@ struct AdamArgs {
     float* p; const float* g; float* m; float* v; float* tgt;
     int64_t n;
     float step_size, bc2_sqrt, one_m_b1, b2, one_m_b2, eps, max_norm, tau, one_m_tau;
-    const double* part;
+    const double* part;         // partial sums of squares of the gradient (another launch made them), fixed order
+    int npart;
     float* gnorm_out;
 };
 
@@ -35,28 +36,38 @@ struct AdamArgs {
 // the float4s t, t + 256, ...; wave shuffle; four wave sums), instead of reading partials a separate launch made:
 // for a parameter buffer that sits in L2 the redundant read costs ~1 us and saves a launch on the step's chain.
 constexpr int64_t FUSED_NORM_MAX = 1 << 18;        // floats (1 MB): gru/gru/gru and conv/conv/mlp networks
+constexpr int ADAM_THREADS = 1024;
 template <bool FUSED_NORM>
-__global__ __launch_bounds__(256) void clip_adam_polyak_kernel(AdamArgs a) {
+__global__ __launch_bounds__(ADAM_THREADS) void clip_adam_polyak_kernel(AdamArgs a) {
     __shared__ float s_coef;
-    __shared__ double s_red[4];
+    __shared__ double s_red[ADAM_THREADS / 64];
     if (FUSED_NORM) {
         const int64_t n4 = a.n >> 2;
         double acc = 0.0;
-        for (int64_t i = threadIdx.x; i < n4; i += 256) {
-            const float4 v = reinterpret_cast<const float4*>(a.g)[i];
-            acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 8 * ADAM_THREADS) {     // eight loads in flight, summed in index order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + u * ADAM_THREADS;
+                v[u] = i < n4 ? reinterpret_cast<const float4*>(a.g)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc += (double)v[u].x * v[u].x + (double)v[u].y * v[u].y + (double)v[u].z * v[u].z + (double)v[u].w * v[u].w;
         }
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float total = (float)sqrt((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+            double t = 0.0;
+            for (int i = 0; i < ADAM_THREADS / 64; ++i) t += s_red[i];
+            const float total = (float)sqrt(t);
             s_coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
             if (blockIdx.x == 0 && a.gnorm_out) *a.gnorm_out = total;
         }
     } else if (threadIdx.x < 64) {                // every block folds the same 256 partials, same order
         double acc = 0.0;
-        for (int i = threadIdx.x; i < NPART; i += 64) acc += a.part[i];
+        for (int i = threadIdx.x; i < a.npart; i += 64) acc += a.part[i];
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if (threadIdx.x == 0) {
             const float total = (float)sqrt(acc);
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256) void clip_adam_polyak_kernel(AdamArgs a) {
     // python-float hyper-parameters: 1 - beta is formed in fp64 and THEN rounded, as torch does
     const float one_m_b1 = a.one_m_b1, one_m_b2 = a.one_m_b2;
     const float tau = a.tau, one_m_tau = a.one_m_tau;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * ADAM_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * ADAM_THREADS) {
         float4 p = reinterpret_cast<float4*>(a.p)[i];
         const float4 g4 = reinterpret_cast<const float4*>(a.g)[i];
         float4 m = reinterpret_cast<float4*>(a.m)[i];
@@ -121,18 +132,23 @@ using namespace mctsq;
 
 extern "C" int64_t mctsq_optim_workspace_bytes(void) { return (int64_t)(NPART * sizeof(double)); }
 
-extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
-                                      float* d_target, int64_t n, int64_t step, double lr, double beta1,
-                                      double beta2, double eps, double max_norm, double tau, float* d_gnorm,
-                                      void* d_ws, int64_t ws_bytes, void* stream) {
+// d_sumsq_parts != NULL: the pieces of the gradient's sum of squares already exist (mctsq_dqn_grad_prepared made
+// them while it reduced the gradient), so no pass over the gradient is needed for the norm
+extern "C" int mctsq_clip_adam_polyak_ex(float* d_params, const float* d_grad, float* d_m, float* d_v,
+                                         float* d_target, int64_t n, int64_t step, double lr, double beta1,
+                                         double beta2, double eps, double max_norm, double tau, float* d_gnorm,
+                                         const double* d_sumsq_parts, int64_t nparts, void* d_ws, int64_t ws_bytes,
+                                         void* stream) {
     MCTSQ_CHECK(d_params && d_grad && d_m && d_v, "NULL device pointer");
     MCTSQ_CHECK(n > 0 && n % 16 == 0, "flat buffer length must be a positive multiple of 16 (padded layout)");
     MCTSQ_CHECK(step >= 1, "Adam step is 1-based");
-    MCTSQ_CHECK(d_ws && ws_bytes >= mctsq_optim_workspace_bytes(), "workspace must hold mctsq_optim_workspace_bytes()");
+    MCTSQ_CHECK(d_sumsq_parts ? (nparts >= 1 && nparts < ((int64_t)1 << 30))
+                              : (d_ws && ws_bytes >= mctsq_optim_workspace_bytes()),
+                "workspace must hold mctsq_optim_workspace_bytes() (or pass the gradient-norm parts)");
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)d_ws;
-    const bool fused = n <= FUSED_NORM_MAX;
-    if (!fused) hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NPART), dim3(256), 0, st, d_grad, n, part);
+    const bool fused = !d_sumsq_parts && n <= FUSED_NORM_MAX;
+    if (!fused && !d_sumsq_parts) hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NPART), dim3(256), 0, st, d_grad, n, part);
     AdamArgs a;
     a.p = d_params; a.g = d_grad; a.m = d_m; a.v = d_v; a.tgt = tau >= 0.0 ? d_target : nullptr;
     a.n = n;
@@ -141,12 +157,22 @@ extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, floa
     a.bc2_sqrt = (float)sqrt(bc2);
     a.one_m_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_m_b2 = (float)(1.0 - beta2);
     a.eps = (float)eps; a.max_norm = (float)max_norm; a.tau = (float)tau; a.one_m_tau = (float)(1.0 - tau);
-    a.part = part; a.gnorm_out = d_gnorm;
+    a.part = d_sumsq_parts ? d_sumsq_parts : part; a.npart = d_sumsq_parts ? (int)nparts : NPART;
+    a.gnorm_out = d_gnorm;
     MCTSQ_CHECK(tau < 0.0 || d_target, "target buffer is NULL but tau >= 0");
-    if (fused) hipLaunchKernelGGL(clip_adam_polyak_kernel<true>, dim3(stream_grid(n >> 2)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(clip_adam_polyak_kernel<false>, dim3(stream_grid(n >> 2)), dim3(256), 0, st, a);
+    const unsigned agrid = (stream_grid(n >> 2) * 256 + ADAM_THREADS - 1) / ADAM_THREADS;
+    if (fused) hipLaunchKernelGGL(clip_adam_polyak_kernel<true>, dim3(agrid), dim3(ADAM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(clip_adam_polyak_kernel<false>, dim3(agrid), dim3(ADAM_THREADS), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int mctsq_clip_adam_polyak(float* d_params, const float* d_grad, float* d_m, float* d_v,
+                                      float* d_target, int64_t n, int64_t step, double lr, double beta1,
+                                      double beta2, double eps, double max_norm, double tau, float* d_gnorm,
+                                      void* d_ws, int64_t ws_bytes, void* stream) {
+    return mctsq_clip_adam_polyak_ex(d_params, d_grad, d_m, d_v, d_target, n, step, lr, beta1, beta2, eps, max_norm, tau,
+                                     d_gnorm, nullptr, 0, d_ws, ws_bytes, stream);
 }
 
 extern "C" int mctsq_polyak(const float* d_params, float* d_target, int64_t n, double tau, void* stream) {

@@ -95,16 +95,18 @@ __device__ u64 prefix_mass(const u64* tree, const PerTree& T, int64_t n, int lan
 }
 
 // ------------------------------------------------------------------ sample
-// One workgroup = SMP_DRAWS draws, four per wave.  The two top levels of the tree (<= 64 + 4096 nodes) are staged
-// in LDS once per workgroup; below them every level costs one 512-byte node read per draw, and the four draws of a
-// wave have their reads in flight together.  A wave scans a node with a 64-wide integer prefix sum (shuffles).
+// One workgroup = SMP_DRAWS draws, one per wave (the descent is a chain of dependent node reads and 64-wide integer
+// prefix scans: latency, so draws run side by side on as many waves as possible rather than in turn on few).  The
+// two top levels of the tree (<= 64 + 4096 nodes) are staged in LDS once per workgroup; below them every level
+// costs one 512-byte node read per draw.
 // Optional tails, all in the same launch:
 //   - gather (ga.phys == this kernel's phys_out): the wave that found a slot copies its 2 x 96-float record into
 //     the six window tensors (per_gather_kernel's job);
 //   - IS-weight normalisation (a.w != NULL): the workgroup whose ticket shows it is the last one to finish divides
 //     all B raw weights by their maximum.  Raw weights travel as write-through (sc1) stores and are read back
 //     with sc1 loads behind the ticket, so no cache maintenance is needed (MI355X_MICROARCH.md, hand-off table).
-constexpr int SMP_DRAWS = 16, SMP_PER_WAVE = 4, SMP_L2MAX = 4096;
+constexpr int SMP_DRAWS = 16, SMP_PER_WAVE = 1, SMP_WAVES = SMP_DRAWS / SMP_PER_WAVE, SMP_THREADS = 64 * SMP_WAVES;
+constexpr int SMP_L2MAX = 4096;
 constexpr int64_t SMP_FUSED_NORM_MAX = 16384;      // beyond this many draws the normalisation is its own launch
 
 struct PerSampleArgs {
@@ -134,17 +136,17 @@ __device__ __forceinline__ void gather_record(const PerGatherArgs& a, int64_t b,
     if (lane == 0) { a.act[b] = a.actions[phys]; a.rew[b] = a.rewards[phys]; a.done[b] = a.dones[phys]; }
 }
 
-__global__ __launch_bounds__(256) void per_sample_kernel(PerSampleArgs a) {
+__global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a) {
     __shared__ u64 s_l2[SMP_L2MAX];
     __shared__ u64 s_head;
-    __shared__ double s_red[4];
+    __shared__ double s_red[SMP_WAVES];
     __shared__ unsigned s_last;
     const PerTree& T = a.T;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int top = T.nlev - 1;
     const bool l2_staged = top >= 1 && T.cnt[top - 1] <= SMP_L2MAX;
     if (l2_staged)
-        for (int i = tid; i < (int)T.cnt[top - 1]; i += 256) s_l2[i] = a.tree[T.off[top - 1] + i];
+        for (int i = tid; i < (int)T.cnt[top - 1]; i += SMP_THREADS) s_l2[i] = a.tree[T.off[top - 1] + i];
     if (a.head != 0 && wv == 0) {                            // logical order starts at `head`
         const u64 H = prefix_mass(a.tree, T, a.head, lane);
         if (lane == 0) s_head = H;
@@ -205,6 +207,14 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerSampleArgs a) {
             g[k] = g[k] * 64 + c;
         }
     }
+    // the sampled records start their trip before the (long, fp64) weight arithmetic of lane 0
+    if (a.ga.states) {
+#pragma unroll
+        for (int k = 0; k < SMP_PER_WAVE; ++k) {
+            const int64_t d = d0 + k;
+            if (d < a.B) gather_record(a.ga, d, live[k] ? (g[k] < a.cap ? g[k] : a.cap - 1) : 0, lane);
+        }
+    }
     // lane k finishes draw k: indices and the raw IS weight (N p_i / sum p)^-beta
     double wraw = 0.0;
     {
@@ -231,18 +241,10 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerSampleArgs a) {
             __hip_atomic_store(&a.w64[d], wraw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (a.ga.states) {
-#pragma unroll
-        for (int k = 0; k < SMP_PER_WAVE; ++k) {
-            const int64_t d = d0 + k;
-            if (d < a.B) gather_record(a.ga, d, live[k] ? (g[k] < a.cap ? g[k] : a.cap - 1) : 0, lane);
-        }
-    }
     if (!a.w && !a.wmax) return;
     // ---- workgroup maximum of the raw weights, then the ticket -------------------------------------------
     double mx = wraw;
     for (int dd = 2; dd >= 1; dd >>= 1) mx = fmax(mx, __shfl_xor(mx, dd, 64));
-    if (lane == 0) s_red[wv] = mx;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's sc1 stores have left before it signals
     __syncthreads();
     if (tid == 0) {
@@ -252,15 +254,16 @@ __global__ __launch_bounds__(256) void per_sample_kernel(PerSampleArgs a) {
     __syncthreads();
     if (!s_last) return;
     mx = 0.0;
-    for (int64_t i = tid; i < a.B; i += 256)
+    for (int64_t i = tid; i < a.B; i += SMP_THREADS)
         mx = fmax(mx, __hip_atomic_load(&a.w64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     for (int dd = 32; dd >= 1; dd >>= 1) mx = fmax(mx, __shfl_xor(mx, dd, 64));
-    __syncthreads();
     if (lane == 0) s_red[wv] = mx;
     __syncthreads();
-    mx = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    mx = s_red[0];
+#pragma unroll
+    for (int i = 1; i < SMP_WAVES; ++i) mx = fmax(mx, s_red[i]);
     if (a.w)
-        for (int64_t i = tid; i < a.B; i += 256)
+        for (int64_t i = tid; i < a.B; i += SMP_THREADS)
             a.w[i] = mx > 0.0 ? (float)(__hip_atomic_load(&a.w64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / mx) : 0.0f;
     if (tid == 0) {
         if (a.wmax) *a.wmax = mx;
@@ -429,40 +432,59 @@ __global__ __launch_bounds__(256) void per_update_kernel(u64* __restrict__ tree,
     set_leaf(tree, T, phys, mctsq_mass(p, alpha, shift));
 }
 
-// Both passes in ONE workgroup for batches up to UPD_FUSED_MAX (the training batch): the marks of all positions are
-// made before any position writes because a workgroup barrier separates them, and the mass deltas of the two top
-// levels (<= 64 + 4096 nodes, where every update of the batch collides) are first summed in LDS, so each of those
-// nodes receives one global add per launch instead of one per update.
-constexpr int UPD_FUSED_MAX = 4096;
+// The whole update in ONE workgroup for batches up to UPD_FUSED_MAX (the training batch).  "Last duplicate wins"
+// is resolved in LDS with an exact open-addressing table keyed by the physical slot (linear probing, load <= 1/4):
+// every position claims / finds its slot's entry with a 64-bit compare-and-swap and raises the entry's mark with
+// atomicMax(position); after the barrier the position that equals the mark is the one that writes.  The mass
+// deltas of the two top tree levels (<= 64 + 4096 nodes, where every update of the batch collides) are first
+// summed in LDS, so each of those nodes receives one global add per launch instead of one per update.  The
+// stamp array is not used on this path.
+constexpr int UPD_FUSED_MAX = 2048, UPD_HASH = 8192;
 __global__ __launch_bounds__(1024) void per_update_fused_kernel(u64* __restrict__ tree, PerTree T,
-                                                                double* __restrict__ prio,
-                                                                int32_t* __restrict__ stamp, int64_t cap,
+                                                                double* __restrict__ prio, int64_t cap,
                                                                 int64_t head, int64_t size,
                                                                 const int64_t* __restrict__ idx,
                                                                 const float* __restrict__ newp, int64_t B,
                                                                 double alpha, int shift) {
     __shared__ u64 s_top[64], s_l2[SMP_L2MAX];
+    __shared__ u64 s_key[UPD_HASH];
+    __shared__ int s_mark[UPD_HASH];
     const int tid = threadIdx.x, top = T.nlev - 1;
     const bool lds_top = top >= 1, lds_l2 = top >= 2 && T.cnt[top - 1] <= SMP_L2MAX;
+    constexpr u64 EMPTY = ~0ull;
     if (tid < 64) s_top[tid] = 0;
     if (lds_l2) for (int i = tid; i < (int)T.cnt[top - 1]; i += 1024) s_l2[i] = 0;
-    for (int64_t i = tid; i < B; i += 1024) {
-        const int64_t li = idx[i];
-        if (li < 0 || li >= size) continue;
-        int64_t phys = head + li;
-        if (phys >= cap) phys -= cap;
-        atomicMax(&stamp[phys], (int32_t)i);
+    for (int i = tid; i < UPD_HASH; i += 1024) { s_key[i] = EMPTY; s_mark[i] = -1; }
+    __syncthreads();
+    // positions tid and tid + 1024 (B <= 2048): physical slot and table entry kept in registers across the barrier
+    int64_t physv[2]; int ent[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 1024 * u;
+        physv[u] = -1; ent[u] = -1;
+        if (i < (int)B) {
+            const int64_t li = idx[i];
+            if (li >= 0 && li < size) {
+                int64_t phys = head + li;
+                if (phys >= cap) phys -= cap;
+                physv[u] = phys;
+                int h = (int)(((u64)phys * 0x9E3779B97F4A7C15ull) >> (64 - 13));
+                for (;;) {
+                    const u64 prev = atomicCAS(&s_key[h], EMPTY, (u64)phys);
+                    if (prev == EMPTY || prev == (u64)phys) break;
+                    h = (h + 1) & (UPD_HASH - 1);
+                }
+                ent[u] = h;
+                atomicMax(&s_mark[h], i);
+            }
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                         // every mark of the batch has been performed
-    for (int64_t i = tid; i < B; i += 1024) {
-        const int64_t li = idx[i];
-        if (li < 0 || li >= size) continue;
-        int64_t phys = head + li;
-        if (phys >= cap) phys -= cap;
-        // read the final mark where the atomics executed: repeating this position's own max returns it unchanged
-        if (atomicMax(&stamp[phys], (int32_t)i) != (int32_t)i) continue;
-        stamp[phys] = -1;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 1024 * u;
+        const int64_t phys = physv[u];
+        if (phys < 0 || s_mark[ent[u]] != i) continue;
         const double p = (double)newp[i];
         prio[phys] = p;
         const u64 m = mctsq_mass(p, alpha, shift);
@@ -579,7 +601,7 @@ static int sample_launch(PerSampleArgs& a, void* ws, hipStream_t st) {
     const bool fused_norm = (a.w || a.wmax) && a.B <= SMP_FUSED_NORM_MAX && ws != nullptr;
     float* w = a.w; double* wmax = a.wmax;
     if (!fused_norm) { a.w = nullptr; a.wmax = nullptr; }
-    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((a.B + SMP_DRAWS - 1) / SMP_DRAWS)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((a.B + SMP_DRAWS - 1) / SMP_DRAWS)), dim3(SMP_THREADS), 0, st, a);
     if (!fused_norm && w) hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, w, wmax);
     else if (!fused_norm && wmax) hipLaunchKernelGGL(per_weight_max_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, wmax);
     MCTSQ_HIP(hipGetLastError());
@@ -666,8 +688,8 @@ int launch_per_update(u64* tree, double* prio, int32_t* stamp, int64_t cap, int6
     if (per_tree_desc(cap, &T)) return -1;
     const int shift = per_mass_shift(mass_cap);
     if (B <= UPD_FUSED_MAX) {
-        hipLaunchKernelGGL(per_update_fused_kernel, dim3(1), dim3(1024), 0, st, tree, T, prio, stamp, cap, head, size,
-                           idx, newp, B, alpha, shift);
+        hipLaunchKernelGGL(per_update_fused_kernel, dim3(1), dim3(1024), 0, st, tree, T, prio, cap, head, size, idx, newp,
+                           B, alpha, shift);
     } else {
         const dim3 grid((unsigned)((B + 255) / 256));
         hipLaunchKernelGGL(per_update_mark_kernel, grid, dim3(256), 0, st, stamp, cap, head, size, idx, B);

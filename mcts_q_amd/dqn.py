@@ -342,10 +342,16 @@ class DQNModel:
         learning_starts) transitions, else the scalar loss (0-dim device tensor)."""
         if len(self.replay_buffer) < self.batch_size or len(self.replay_buffer) < self.learning_starts:
             return None
-        batch, w, idx = self.replay_buffer.sample_device(self.batch_size)
-        abs_td = self.learner.compute_grad(batch, w)
-        self.learner.apply_grad(tau=None)
-        self.replay_buffer.update_priorities(idx, abs_td)
+        rb = self.replay_buffer
+        rb.flush()
+        u = np.random.random_sample(int(self.batch_size))     # the stream np.random.choice draws from (:292)
+        if self.learner.world == 1:                           # the whole step is one library call
+            self.learner.step(rb.dev, u)
+        else:
+            batch, w, idx, _ = rb.dev.sample_batch(u)
+            abs_td = self.learner.compute_grad(batch, w)
+            self.learner.apply_grad(tau=None)
+            rb.dev.update_priorities(idx, abs_td)
         return self.learner.loss[0].clone()
 
     def update_target_network(self, tau: float = 0.005) -> None:

@@ -11,7 +11,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, ptr, MctsqError
+from ._lib import lib, ptr, MctsqError, StepArgs
 from .netdesc import NetSpec
 from .parallel import all_reduce
 from .qnet import DeviceQNet
@@ -41,9 +41,31 @@ class DeviceLearner:
         self._small = torch.zeros(int(lib.mctsq_optim_workspace_bytes()), dtype=torch.uint8,
                                   device=self.device)                             # grad-norm partials
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # weights as the kernels multiply by them (split bf16 fragments), refreshed once per parameter change by ONE
+        # launch: the policy's / target's forward fragments live in their DeviceQNet (leaf evaluation between steps
+        # uses the policy's), the backward fragments here
+        nb = lib.check(lib.mctsq_dqn_prepared_bwd_bytes(C.byref(self.desc)))
+        self._prep_bwd = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.device)
+        self._prep_versions = None
+        nparts = lib.check(lib.mctsq_dqn_grad_sumsq_parts(C.byref(self.desc)))
+        self._sumsq_parts = torch.zeros(nparts, dtype=torch.float64, device=self.device)
+        self._n_sumsq = C.c_int64(0)
 
     def _st(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _prepare(self):
+        lib.check(lib.mctsq_dqn_prepare(C.byref(self.desc), ptr(self.policy.flat), ptr(self.target.flat),
+                                        ptr(self.policy._prep), ptr(self.target._prep), ptr(self._prep_bwd), self._st()))
+        self._prep_versions = (self.policy.flat._version, self.target.flat._version)
+        self.policy._prep_version, self.target._prep_version = self._prep_versions
+
+    def _ensure_prepared(self):
+        """Torch ops on the flat buffers (load_state_dict, copy_) move their version counters; the library's own
+        kernels (Adam, Polyak) do not, so their callers here re-prepare right behind them."""
+        if (self._prep_versions != (self.policy.flat._version, self.target.flat._version)
+                or self.policy._prep_version is None or self.target._prep_version is None):
+            self._prepare()
 
     def load_state_dict(self, sd, target_sd=None):
         self.policy.load_state_dict(sd)
@@ -86,13 +108,18 @@ class DeviceLearner:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         abs_td = torch.empty(B, dtype=torch.float32, device=self.device)
         # loss_scale = B_local / B_global: gradient and loss of this rank's rows as their share of the global mean
-        lib.check(lib.mctsq_dqn_grad(
+        self._ensure_prepared()
+        single = self.world == 1                # the reduction's norm pieces are those of the FINAL gradient
+        lib.check(lib.mctsq_dqn_grad_prepared(
             C.byref(self.desc), ptr(self.policy.flat), ptr(self.target.flat),
+            ptr(self.policy._prep), ptr(self.target._prep), ptr(self._prep_bwd),
             ptr(batch["sprice"]), ptr(batch["sprocess"]), ptr(batch["sgas"]),
             ptr(batch["nprice"]), ptr(batch["nprocess"]), ptr(batch["ngas"]),
             ptr(batch["act"]), ptr(batch["rew"]), ptr(batch["done"]), ptr(isw),
             self.gamma, B / float(global_batch), B, ptr(self.grad), ptr(self.loss), ptr(abs_td), None, None,
+            ptr(self._sumsq_parts) if single else None, C.addressof(self._n_sumsq),
             ptr(self._ws), self._ws.numel(), self._st()))
+        self._have_sumsq = single
         if self.world > 1:                      # data-parallel: ONE all-reduce (RCCL) over [gradient | loss]
             all_reduce(self._gradbuf, group=self.group)
         return abs_td
@@ -102,15 +129,61 @@ class DeviceLearner:
         """tau None: no target update in this call; 0 < tau <= 1: Polyak (1.0 = hard copy)."""
         self.step_count += 1
         n = self.spec.n_flat
-        lib.check(lib.mctsq_clip_adam_polyak(
+        parts = getattr(self, "_have_sumsq", False)
+        lib.check(lib.mctsq_clip_adam_polyak_ex(
             ptr(self.policy.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
             ptr(self.target.flat), n, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
             self.max_grad_norm, -1.0 if tau is None else float(tau), ptr(self.grad_norm),
+            ptr(self._sumsq_parts) if parts else None, self._n_sumsq.value if parts else 0,
             ptr(self._small), self._small.numel(), self._st()))
-        self.policy.mark_dirty()
-        self.target.mark_dirty()
+        self._have_sumsq = False                # the pieces describe one gradient, used once
+        self._prepare()                         # policy (and target) changed: one launch refreshes every fragment
+
+    # ---- DQNModel.update() as ONE library call (dqn_per.py:401-476) ---------------------------------
+    def step(self, replay, u, tau: float | None = None, beta: float = 0.4):
+        """sample (uniforms `u`, fp64 [B], device tensor or host array) -> batch -> gradient -> clip / Adam
+        (-> Polyak when tau is given) -> priority write-back on `replay` (a DevicePER on this device), enqueued by
+        one call of mctsq_per_dqn_step.  Single-GPU path; data-parallel runs use compute_grad / apply_grad around
+        their all-reduce.  Leaves the loss in self.loss."""
+        if self.world != 1:
+            raise MctsqError("DeviceLearner.step is the single-GPU path; use compute_grad/apply_grad when data-parallel")
+        if replay.size == 0:
+            raise ValueError("cannot sample from an empty buffer")
+        u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
+        B = int(u.numel())
+        self._ensure_prepared()
+        a = getattr(self, "_step_args", None)
+        if a is None or self._step_B != B or self._step_replay is not replay:
+            need = lib.check(lib.mctsq_per_dqn_step_workspace_bytes(C.byref(self.desc), B))
+            self._step_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            off = (-self._step_ws.data_ptr()) % 256
+            a = StepArgs()
+            a.d_ws, a.ws_bytes = self._step_ws.data_ptr() + off, need
+            a.d_params, a.d_target_params, a.d_grad = ptr(self.policy.flat), ptr(self.target.flat), ptr(self.grad)
+            a.d_m, a.d_v = ptr(self.exp_avg), ptr(self.exp_avg_sq)
+            a.d_prep_policy, a.d_prep_target, a.d_prep_bwd = ptr(self.policy._prep), ptr(self.target._prep), ptr(self._prep_bwd)
+            a.d_loss, a.d_gnorm = ptr(self.loss), ptr(self.grad_norm)
+            a.B = B
+            self._step_args, self._step_B, self._step_replay = a, B, replay
+        r = replay
+        ws = r._ws_for(B)
+        a.d_tree, a.d_prio, a.d_stamp = ptr(r.tree), ptr(r.prio), ptr(r.stamp)
+        a.d_states, a.d_next_states, a.d_actions = ptr(r.states), ptr(r.next_states), ptr(r.actions)
+        a.d_rewards, a.d_dones = ptr(r.rewards), ptr(r.dones)
+        a.capacity, a.head, a.size, a.mass_capacity = r.capacity, r.head, r.size, r.mass_capacity
+        a.alpha, a.beta = r.alpha, float(beta)
+        a.d_per_ws, a.per_ws_bytes, a.d_wmax = ptr(ws), ws.numel(), ptr(r.last_local_wmax)
+        a.gamma, a.lr, a.beta1, a.beta2, a.eps = self.gamma, self.lr, self.betas[0], self.betas[1], self.eps
+        a.max_norm, a.tau = self.max_grad_norm, (-1.0 if tau is None else float(tau))
+        self.step_count += 1
+        a.adam_step = self.step_count
+        a.d_u = ptr(u)
+        lib.check(lib.mctsq_per_dqn_step(C.byref(self.desc), C.byref(a), self._st()))
+        self._prep_versions = (self.policy.flat._version, self.target.flat._version)   # the call re-prepared them
+        self.policy._prep_version, self.target._prep_version = self._prep_versions
+        r._max_dirty = True
 
     def update_target(self, tau: float = 1.0):
         lib.check(lib.mctsq_polyak(ptr(self.policy.flat), ptr(self.target.flat), self.spec.n_flat, float(tau),
                                    self._st()))
-        self.target.mark_dirty()
+        self._prepare()

@@ -270,3 +270,75 @@ def test_gradient_nonstandard_shapes(case):
     for k, ref in grads.items():
         gs = max(float(ref.abs().max()), 1e-3 * gmax)
         assert np.abs(got[k] - ref.numpy()).max() <= 2e-4 * gs, k
+
+
+def _filled_replay(n=3000, cap=4096, seed=2):
+    from mcts_q_amd.per import DevicePER
+    g = torch.Generator().manual_seed(seed)
+    buf = DevicePER(cap)
+    buf.push_rows(torch.rand(n, 91, generator=g).numpy(), torch.randint(0, 5, (n,), generator=g).numpy(),
+                  torch.rand(n, generator=g).numpy(), torch.rand(n, 91, generator=g).numpy(),
+                  (torch.rand(n, generator=g) < 0.1).float().numpy())
+    buf.update_priorities(np.arange(n), torch.rand(n, generator=g).numpy() + 0.01)
+    return buf
+
+
+@pytest.mark.parametrize("combo", [("gru", "gru", "gru"), ("conv", "gru", "mlp")])
+def test_one_call_step_equals_the_separate_entry_points(combo):
+    """mctsq_per_dqn_step (DQNModel.update as one library call) against sample_batch -> dqn_grad_prepared ->
+    clip_adam_polyak_ex -> prepare -> per_update called one by one: parameters, Adam moments, target, priorities
+    and loss bit for bit over three steps (ragged batch: 100 is not a multiple of the 16-row tile)."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.learner import DeviceLearner
+    cfg = dict(price=combo[0], process=combo[1], gas=combo[2], act="relu", flavor="per")
+    torch.manual_seed(5)
+    sd = {k: v.detach().numpy() for k, v in torch_ref.RefQNet(cfg).state_dict().items()}
+    spec = NetSpec.from_cfg(cfg)
+    A, Bm = DeviceLearner(spec).load_state_dict(sd), DeviceLearner(spec).load_state_dict(sd)
+    ra, rb = _filled_replay(), _filled_replay()
+    rng = np.random.RandomState(8)
+    for it in range(3):
+        u = rng.random_sample(100)
+        A.step(ra, u, tau=0.005)
+        batch, w, idx, _ = rb.sample_batch(u)
+        abs_td = Bm.compute_grad(batch, w)
+        Bm.apply_grad(tau=0.005)
+        rb.update_priorities(idx, abs_td)
+        torch.cuda.synchronize()
+        assert torch.equal(A.loss, Bm.loss) and float(A.loss) > 0
+        for x, y in ((A.policy.flat, Bm.policy.flat), (A.target.flat, Bm.target.flat), (A.exp_avg, Bm.exp_avg),
+                     (A.exp_avg_sq, Bm.exp_avg_sq), (A.grad, Bm.grad), (ra.prio, rb.prio), (ra.tree, rb.tree),
+                     (A.grad_norm, Bm.grad_norm)):
+            assert torch.equal(x, y)
+    assert A.step_count == Bm.step_count == 3
+    # the forward fragments the step left behind are those of the new parameters (leaf evaluation uses them as is)
+    p, c, g = torch.rand(7, 25, 1).cuda(), torch.rand(7, 10, 6).cuda(), torch.rand(7, 3, 2).cuda()
+    q1 = A.policy(p, c, g)["q"].clone()
+    A.policy.mark_dirty()
+    assert torch.equal(q1, A.policy(p, c, g)["q"])
+
+
+def test_unprepared_gradient_entry_point_gives_the_same_bits():
+    """mctsq_dqn_grad (splits the weights itself, into its workspace) == mctsq_dqn_grad_prepared."""
+    import ctypes as C
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd._lib import lib, ptr
+    from mcts_q_amd.learner import DeviceLearner
+    cfg = dict(price="gru", process="gru", gas="gru", act="relu", flavor="per")
+    torch.manual_seed(6)
+    sd = {k: v.detach().numpy() for k, v in torch_ref.RefQNet(cfg).state_dict().items()}
+    L = DeviceLearner(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    buf = _filled_replay()
+    batch, w, _, _ = buf.sample_batch(np.random.RandomState(1).random_sample(48))
+    abs_td = L.compute_grad(batch, w)
+    g_ref, loss_ref = L.grad.clone(), L.loss.clone()
+    need = lib.check(lib.mctsq_dqn_grad_workspace_bytes(C.byref(L.desc), 48))
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    grad, loss, td = torch.empty_like(L.grad), torch.zeros(1, device="cuda"), torch.empty(48, device="cuda")
+    lib.check(lib.mctsq_dqn_grad(C.byref(L.desc), ptr(L.policy.flat), ptr(L.target.flat), ptr(batch["sprice"]),
+                                 ptr(batch["sprocess"]), ptr(batch["sgas"]), ptr(batch["nprice"]), ptr(batch["nprocess"]),
+                                 ptr(batch["ngas"]), ptr(batch["act"]), ptr(batch["rew"]), ptr(batch["done"]), ptr(w),
+                                 L.gamma, 1.0, 48, ptr(grad), ptr(loss), ptr(td), None, None, ptr(ws), ws.numel(),
+                                 torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(grad, g_ref) and torch.equal(loss, loss_ref) and torch.equal(td, abs_td)

@@ -23,16 +23,21 @@ buf.push_rows(torch.rand(N, 91, device="cuda"), torch.randint(0, 5, (N,), device
 buf.update_priorities(torch.arange(N, device="cuda"), torch.rand(N, device="cuda") + 0.01)
 u = torch.from_numpy(np.random.RandomState(0).random_sample((K + 10, B))).cuda()
 def step(i):
-    batch, w, idx, _ = buf.sample_batch(u[i])
-    abs_td = L.compute_grad(batch, w)
-    L.apply_grad(tau=0.005)
-    buf.update_priorities(idx, abs_td)
+    if os.environ.get("MCTSQ_MODULAR"):
+        batch, w, idx, _ = buf.sample_batch(u[i])
+        abs_td = L.compute_grad(batch, w)
+        L.apply_grad(tau=0.005)
+        buf.update_priorities(idx, abs_td)
+    else:
+        L.step(buf, u[i], tau=0.005)
 for i in range(10):
     step(i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(K):
     step(10 + i)
+t_host = time.perf_counter() - t0            # the host has enqueued everything; the device may still be busy
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+print(f"host enqueue {t_host / K * 1e3:.3f} ms/step")
 print(f"{combo} B={B}: {dt / K * 1e3:.3f} ms/step, {K / dt:.0f} steps/s, loss {L.loss.item():.5f}")
