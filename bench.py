@@ -262,18 +262,18 @@ def main():
                         "ceiling is 2500/6 = 417 TFLOP/s fp32-equivalent; `frac_executed_pipe` prices the kernel against "
                         "that ceiling blended with the fp32-MFMA share (input projections)"}
 
-    # --- the same K steps with the D2H of value / greedy action inside the timed region -----------
-    va = torch.empty(2 * B, dtype=torch.float32, device=dev)            # vmax | argmax in one buffer: one copy
-    out_d = dict(q=out["q"], vmax=va[:B], argmax=va[B:].view(torch.int32), prior=out["prior"])
+    # --- the same K steps with the D2H of value / greedy action inside the timed region: the kernel's
+    # epilogue stores vmax / argmax straight into pinned (device-mapped) host memory, so the transfer is part of the
+    # launch and needs no copy of its own (an async copy per step was measured at +47 us per step) -----------
     host_va = torch.empty(2 * B, dtype=torch.float32, pin_memory=True)
+    out_d = dict(q=out["q"], vmax=host_va[:B], argmax=host_va[B:].view(torch.int32), prior=out["prior"])
     for _ in range(max(3, args.warmup // 4)):
         net(price, process, gas, out=out_d)
-        host_va.copy_(va, non_blocking=True)
     barrier()
+    assert torch.equal(host_va[:B], out["vmax"].cpu()) and torch.equal(host_va[B:].view(torch.int32), out["argmax"].cpu())
     t0d = time.perf_counter()
     for _ in range(args.steps):
         net(price, process, gas, out=out_d)
-        host_va.copy_(va, non_blocking=True)
     barrier()
     wall_d2h = max_over_ranks(time.perf_counter() - t0d)
 
@@ -396,8 +396,9 @@ def main():
             "gpu_ms_per_step_events": gpu_ms_total / args.steps,
             "with_d2h_of_value_and_action": {"value": world * B * args.steps / wall_d2h, "unit": "leaf evals/s",
                                              "ms_per_step": wall_d2h / args.steps * 1e3,
-                                             "note": "same K steps, each followed by one async D2H of vmax|argmax "
-                                                     "(32 KB) into pinned memory, copies inside the timed region"},
+                                             "note": "same K steps with vmax / argmax (32 KB per step) stored by the "
+                                                     "kernel's epilogue into pinned host memory: the D2H is inside "
+                                                     "the launch, results checked against the device copy"},
             "collective_backend": (dist.get_backend() if world > 1 else None),
             "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
             "roofline": roofline,
