@@ -82,3 +82,42 @@ def test_oracle_encoders_match_reference_classes(tag):
         else:
             got = ORACLE_FN[tag]({k: np.asarray(v, dt) for k, v in sd.items()}, x.astype(dt))
         assert np.abs(got - y).max() <= 1e-5 * np.abs(y).max(), (tag, dt)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="needs the reference tree (dev container only)")
+def test_reference_loads_our_checkpoint():
+    """f-3 interchange, other direction (dqn_per.py:495-508): tests/golden/ckpt_ours_conv_conv_mlp.pt was written on
+    the GPU box by THIS repository's DQNModel.save (tools/make_ckpt_fixture.py); the reference's own DQNModel.load
+    (torch.load + load_state_dict + deque rebuild) reads it and finds the same networks, Adam state and buffer."""
+    import subprocess
+    import sys
+    code = r'''
+import json, sys
+import numpy as np, torch
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+import src.mctsq_config_dqn_per as ref
+z = np.load(sys.argv[2])
+m = ref.DQNModel(el_input_dim=1, process_input_dim=6, gas_eua_input_dim=2, action_dim=5, embed_dim=64, hidden_layers=2,
+                 hidden_units=128, buffer_capacity=64, batch_size=8, gamma=0.99, lr=1e-3, price_encoder_type="conv",
+                 process_encoder_type="conv", gas_eua_encoder_type="mlp", activation="relu", learning_starts=10, seed=1)
+m.load(sys.argv[1])
+for k, v in m.policy_net.state_dict().items():
+    assert np.array_equal(v.numpy(), z["sd/" + k]), k
+for k, v in m.target_net.state_dict().items():
+    assert np.array_equal(v.numpy(), z["tgt/" + k]), k
+assert len(m.replay_buffer) == 40 and m.replay_buffer.buffer.maxlen == 64
+assert np.array_equal(np.array(m.replay_buffer.priorities), z["prio"])
+assert np.array_equal(np.stack([t[0]["Elec_Price"] for t in m.replay_buffer.buffer]), z["price0"])
+assert [t[1] for t in m.replay_buffer.buffer] == list(z["actions"])
+st = m.optimizer.state_dict()["state"]
+assert float(st[0]["step"]) == 1.0 and np.array_equal(st[0]["exp_avg"].numpy(), z["exp_avg0"])
+np.random.seed(5)
+loss = m.update()                       # the reference trains on from the loaded state
+assert loss is not None and np.isfinite(float(loss))
+print("ok", float(loss))
+'''
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(GOLDEN, "ckpt_ours_conv_conv_mlp.pt"),
+                          os.path.join(GOLDEN, "ckpt_ours_conv_conv_mlp.npz")], capture_output=True, text=True,
+                         cwd="/tmp", env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]

@@ -130,3 +130,42 @@ def test_policy_net_call_conventions():
         TripleEncoderDQN(1, 6, 2, 64, 2, 128, 5, "gru", "gru", "conv", "relu")
     with pytest.raises(ValueError):
         TripleEncoderDQN(1, 6, 2, 64, 2, 128, 5, "gru", "gru", "gru", "gelu")
+
+
+def test_loads_a_checkpoint_written_by_the_reference(tmp_path):
+    """f-3 interchange (dqn_per.py:478-508): tests/golden/ckpt_ref_conv_conv_mlp.pt was written by the REFERENCE's
+    DQNModel.save after 40 pushes and one update (tests/golden/gen_golden_r2.py).  DQNModel.load (tensor-only
+    unpickling) restores networks, Adam state and the replay buffer; the next update() then reproduces the
+    reference's own next update: loss, sampled priorities written back, post-step parameters."""
+    z = np.load(os.path.join(GOLDEN, "ckpt_ref_conv_conv_mlp.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    model = build(dict(cfg, seed=11), capacity=cfg["capacity"], B=cfg["B"])      # different seed: all state comes from the file
+    model.load(os.path.join(GOLDEN, "ckpt_ref_conv_conv_mlp.pt"))
+    for k, v in model.policy_net.state_dict().items():
+        assert np.array_equal(v.numpy(), z["sd_saved/" + k]), k
+    for k, v in model.target_net.state_dict().items():
+        assert np.array_equal(v.numpy(), z["tgt_saved/" + k]), k
+    assert len(model.replay_buffer) == len(z["prio_saved"])
+    assert np.array_equal(np.array(model.replay_buffer.priorities), z["prio_saved"])
+    rows = np.stack([np.concatenate([t[0]["Elec_Price"], np.stack([t[0][k] for k in PROC_KEYS], -1).ravel(),
+                                     np.stack([t[0]["Gas_Price"], t[0]["EUA_Price"]], -1).ravel()])
+                     for t in model.replay_buffer.buffer])
+    assert np.array_equal(rows, z["rows_saved"].astype(np.float32))
+    assert model.learner.step_count == 1                                          # Adam step counter from the file
+    np.random.seed(cfg["np_seed_before_update"])
+    loss = model.update()
+    np.testing.assert_allclose(float(loss.item()), float(z["loss2"]), rtol=5e-6)
+    np.testing.assert_allclose(np.array(model.replay_buffer.priorities), z["prio_post"], rtol=1e-4, atol=1e-6)
+    post = model.policy_net.state_dict()
+    for k in post:
+        assert np.abs(post[k].numpy() - z["sd_post/" + k]).max() <= 2.0 * 1e-3, k      # |Adam step| <= lr
+        moved = np.abs(z["sd_post/" + k] - z["sd_saved/" + k]) > 5e-4                 # entries with a clear gradient
+        assert np.abs(post[k].numpy() - z["sd_post/" + k])[moved].max(initial=0) <= 5e-6, k
+    # and a file written here has the reference's layout (the CPU test test_reference_loads_our_checkpoint reads a
+    # committed one with the reference's own loader)
+    f = str(tmp_path / "ours.pt")
+    model.save(f)
+    ck = torch.load(f, map_location="cpu", weights_only=False)
+    assert sorted(ck) == ["optimizer_state_dict", "policy_net_state_dict", "replay_buffer_data", "target_net_state_dict"]
+    assert sorted(ck["replay_buffer_data"]) == ["alpha", "buffer", "capacity", "priorities"]
+    assert list(ck["policy_net_state_dict"]) == list(post)
