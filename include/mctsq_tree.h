@@ -33,6 +33,60 @@ int64_t mctsq_tree_retain(int64_t K, int64_t n, const int64_t* keep_roots, int64
                           double* prior_a, float* rows, int64_t row_w, double* svec, int64_t D, int64_t* rel,
                           int64_t* newid);
 
+/* ---- Vectorised PtG environment step ---------------------------------------------------------
+ * PTGEnv.step of the `_per` environment (env/ptg_gym_env_per.py:422-662, 715-992) is a function of (action, state_c)
+ * and static tables; here it runs over n state VECTORS at once.  One state is D = 12 + 6*seq_length doubles:
+ *   [0] i  [1] j  [2] k  [3] Meth_State  [4] Meth_T_cat  [5] standby_op  [6] startup_op  [7] part_op  [8] full_op
+ *   (data-set ids, order of load_data's op_data_files, src/mctsq_utils.py:126-134: 0 startup_cold .. 16 op12_f_p_f_20)
+ *   [9] hot_cold  [10] episode offset in days (act_ep_d)  [11] cumulative reward
+ *   [12..] the normalised process window [seq_length][6] (T_CAT, H2_in, CH4_syn, H2_res, H2O_DE, Elec_Heating)
+ * Deviations from the reference, all of them state the reference keeps on the environment OBJECT and that therefore
+ * leaks between tree nodes there: hot_cold (:454-457), the noon-updated gas/EUA columns (:597-603, derived from the
+ * clock here) and cum_rew ride in the state vector / are functions of it, i.e. every state sees the values a
+ * sequential episode would give it.  Interval averages use extended-precision prefix sums (np.average: pairwise sums;
+ * agreement ~1e-15 relative).  The random index offset of a mode change (:811, 825, 849) is an argument (noise[n],
+ * already scaled by `noise`), so the step itself is deterministic. */
+typedef struct {
+    int64_t step_size, seq_length, seq_step, sim_step, eps_sim_steps, price_len, H, Dd, scenario3;
+    double convert_mol_to_Nm3, H_u_CH4, H_u_H2, dt_water, cp_water, rho_water, Molar_mass_CO2, Molar_mass_H2O,
+        h_H2O_evap, eeg_el_price, heat_price, o2_price, water_price, min_load_electrolyzer, max_h2_volumeflow, eta_CHP;
+    double t_cat_standby, t_cat_startup_cold, t_cat_startup_hot;
+    double time1_start_p_f, time2_start_f_p, time_p_f, time_f_p, time1_p_f_p, time2_p_f_p, time3_p_f_p, time34_p_f_p,
+        time4_p_f_p, time45_p_f_p, time5_p_f_p, time1_f_p_f, time2_f_p_f, time23_f_p_f, time3_f_p_f, time34_f_p_f,
+        time4_f_p_f, time45_f_p_f, time5_f_p_f, i_fully_developed, j_fully_developed;
+    double lb[9], ub[9];            /* el, gas, eua, T, h2, ch4, h2_res, h2o, heat */
+    double rew_l_b, rew_u_b;
+} mctsq_ptg_params;
+
+#define MCTSQ_PTG_NDS 17
+#define MCTSQ_PTG_STATE_HEAD 12
+
+/* op: the 17 process data sets concatenated, [sum ds_len][7] (time, T_cat, n_h2, n_ch4, n_h2_res, m_DE, Pel);
+ * e_r_b [3][price_len][H], g_e [2][2][Dd] as Preprocessing builds them (src/mctsq_utils.py:300-345).  Everything is
+ * copied.  Returns NULL on bad geometry (a data set shorter than one step, window longer than one step). */
+void* mctsq_ptg_create(const mctsq_ptg_params* p, const double* op, const int64_t* ds_len, const double* e_r_b,
+                       const double* g_e);
+void mctsq_ptg_destroy(void* env);
+/* reset (:664-705, 135-195): states[n][D] for episodes starting at day offsets d0[n] */
+void mctsq_ptg_reset(const void* env, int64_t n, const int64_t* d0, double* states);
+/* observation rows of n states: price[n][price_len], proc[n][6*seq_length], gas[n][6] (gas, eua interleaved per
+ * time), each with its own row stride in floats; meth[n] = Meth_State.  Returns the number of states whose clock
+ * points outside the price tables (the reference raises IndexError there; the caller must). */
+int64_t mctsq_ptg_observe(const void* env, int64_t n, const double* states, float* price, int64_t ld_price,
+                          float* proc, int64_t ld_proc, float* gas, int64_t ld_gas, int64_t* meth);
+/* step (:422-662): next[n][D], observation rows as in observe, reward[n] (normalised, :418), term[n] (:707-712),
+ * meth[n].  actions[n] in 0..4; noise[n] may be NULL (= 0).  Returns the count of out-of-table clocks / bad actions. */
+int64_t mctsq_ptg_step(const void* env, int64_t n, const double* states, const int64_t* actions, const double* noise,
+                       double* next, float* price, int64_t ld_price, float* proc, int64_t ld_proc, float* gas,
+                       int64_t ld_gas, double* reward, uint8_t* term, int64_t* meth);
+/* the evaluation fields of _get_info (:312-340) that are functions of a state: out[n][8] = el_price_act,
+ * gas_price_act, eua_price_act, Pot_Reward, Part_Full, cum_reward, Meth_T_cat, Meth_Hot_Cold */
+int64_t mctsq_ptg_info(const void* env, int64_t n, const double* states, double* out);
+/* D of this environment; and the step of ONE state into caller-provided slots (what mctsq_ptg_step loops over) */
+int64_t mctsq_ptg_state_dim(const void* env);
+int mctsq_ptg_step_one(const void* env, const double* st, int64_t action, double nz, double* nx, float* price,
+                       float* proc, float* gas, double* reward, uint8_t* term, int64_t* meth);
+
 #ifdef __cplusplus
 }
 #endif

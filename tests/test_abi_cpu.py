@@ -48,6 +48,10 @@ def test_host_tree_helper_exports_its_header():
     assert names == ["mctsq_tree_backup", "mctsq_tree_retain", "mctsq_tree_select"]
     dll = ctypes.CDLL(os.path.join(ROOT, "mcts_q_amd", "lib", "libmctsq_tree.so"))
     assert all(hasattr(dll, n) for n in names)
+    env = sorted(set(re.findall(r"\b(mctsq_ptg_[a-z0-9_]+)\s*\(", text)))
+    assert env == ["mctsq_ptg_create", "mctsq_ptg_destroy", "mctsq_ptg_info", "mctsq_ptg_observe", "mctsq_ptg_reset",
+                   "mctsq_ptg_state_dim", "mctsq_ptg_step", "mctsq_ptg_step_one"]
+    assert all(hasattr(dll, n) for n in env)
 
 
 def test_encoder_layout_query_needs_no_gpu():

@@ -26,6 +26,61 @@ def test_shims_export_the_reference_names():
         assert hasattr(per, n), n
         assert hasattr(std, n), n
     assert hasattr(std, "add_time_features") and hasattr(std, "add_time_features_to_gas_eua")
+    import src.mctsq_config_train as tr
+    import src.mctsq_utils as ut
+    assert hasattr(tr, "TrainConfiguration")
+    for n in ("import_market_data", "import_data", "load_data", "Preprocessing", "initial_print", "config_print"):
+        assert hasattr(ut, n), n
+
+
+def test_preprocessing_plumbing_on_synthetic_files(tmp_path):
+    """8f-4: CSV files in the reference's format -> load_data -> Preprocessing -> environment kwargs; the configuration
+    classes raise / assert like the reference's (mctsq_config_train.py:27-59, mctsq_utils.py:156-179)."""
+    import contextlib, io
+    import pandas as pd
+    from mcts_q_amd.envconfig import EnvConfiguration
+    from mcts_q_amd.ptgdata import MARKET_COLUMNS, OP_DATA_FILES, PROCESS_COLUMNS, Preprocessing, TrainConfiguration, load_data
+    from mcts_q_amd.synthetic_env import (PTG_ENV_VALUES, PTG_MCTSQ_VALUES, PTG_TRAIN_VALUES, synthetic_ptg_prices,
+                                          synthetic_ptg_tables)
+    prices, tables = synthetic_ptg_prices(3, train_days=14), synthetic_ptg_tables(3, scale=0.1)
+    ev = dict(PTG_ENV_VALUES, scenario=1)
+    ev["datafile_path"] = dict(path="data/", datafile={f"datafile_path{n}": f"{k}.csv" for k, n in OP_DATA_FILES})
+    os.makedirs(tmp_path / "data" / "OP2")
+    for k, _ in OP_DATA_FILES:
+        pd.DataFrame(tables[k], columns=PROCESS_COLUMNS).to_csv(tmp_path / "data" / "OP2" / f"{k}.csv", sep=";", index=False)
+    for split in ("train", "val", "test"):
+        for short, name in (("el", "el_price"), ("gas", "gas_price"), ("eua", "eua_price")):
+            v = prices[f"{name}_{split}"]
+            step = "h" if short == "el" else "D"
+            t = pd.date_range("2021-01-01", periods=len(v), freq=step).strftime("%d-%m-%Y %H:%M")
+            col, scale = MARKET_COLUMNS[short]
+            pd.DataFrame({"Time": t, col: v / scale}).to_csv(tmp_path / f"{short}_{split}.csv", sep=";", index=False)
+            ev[f"datafile_path_{split}_{short}"] = f"{short}_{split}.csv"
+    ec = EnvConfiguration(values=ev)
+    tc = TrainConfiguration(values=dict(PTG_TRAIN_VALUES), mctsq_values=PTG_MCTSQ_VALUES, env_values=ev)
+    tc.path, tc.seed_train = str(tmp_path), 3654
+    with contextlib.redirect_stdout(io.StringIO()):
+        dp, do = load_data(ec, tc)
+        pre = Preprocessing(dp, do, ec, tc)
+    np.testing.assert_allclose(dp["el_price_train"], prices["el_price_train"], rtol=1e-12)
+    assert np.array_equal(do["cooldown"], tables["cooldown"]) and ec.train_len_d == 8 and pre.n_eps == 2
+    assert pre.e_r_b_train.shape == (3, 25, 14 * 24 - 25) and pre.g_e_val.shape == (2, 2, 5)
+    assert pre.e_r_b_train[0, 7, 100] == dp["el_price_train"][107]
+    assert pre.eps_sim_steps_train == 4 * 144 and pre.eps_sim_steps_test == 5 * 144
+    np.random.seed(3654)
+    first = np.arange(2.0); np.random.shuffle(first)
+    assert np.array_equal(pre.eps_ind[:2], first.astype(int)) and len(pre.eps_ind) == 2 * int(pre.num_loops) * 10
+    kw = pre.dict_env_kwargs("val")
+    assert kw["eps_ind"] is None and kw["eps_sim_steps"] == 5 * 144 and kw["rew_u_b"] == pre.e_r_b_train[1, 0].max()
+    with pytest.raises(ValueError):
+        pre.dict_env_kwargs("eval")
+    with pytest.raises(ValueError):
+        TrainConfiguration(values=dict(PTG_TRAIN_VALUES, com_conf="cloud"), mctsq_values=PTG_MCTSQ_VALUES, env_values=ev)
+    with pytest.raises(AssertionError):
+        TrainConfiguration(values=dict(PTG_TRAIN_VALUES), mctsq_values=dict(seq_length=5, seq_step=10), env_values=ev)
+    ec2 = EnvConfiguration(values=dict(ev, eps_len_d=3))
+    with pytest.raises(AssertionError, match="Possible divisors"):
+        load_data(ec2, tc)
 
 
 def test_time_feature_helpers_match_reference():
