@@ -87,6 +87,35 @@ int64_t mctsq_ptg_state_dim(const void* env);
 int mctsq_ptg_step_one(const void* env, const double* st, int64_t action, double nz, double* nx, float* price,
                        float* proc, float* gas, double* reward, uint8_t* term, int64_t* meth);
 
+/* ---- One search iteration of many trees in ONE call (lock-step driver over the vectorised environment) ----------
+ * Selection, the choice of an untried action, the environment step and the new node, for trees k_lo <= k < k_hi, then
+ * (after the caller evaluated the new leaves on the GPU) value / prior assignment and backup.  Same arithmetic as the
+ * separate calls above and as treesearch.py's numpy path, which restate _select / _expand / _evaluate /
+ * _backpropagate (src/mctsq_config_mcts_per.py:266-381).  The untried action of tree k in iteration `iteration` is
+ * the floor(u * n_untried)-th set bit of legal & ~tried, u from a counter-based generator over (seed, iteration, k):
+ * same distribution as the reference's random.choice (:328), a reproducible stream that does not depend on how
+ * the trees are split over calls.  The caller guarantees f->cap >= f->n + (k_hi - k_lo). */
+typedef struct {
+    int64_t K, cap, n, D, row_w;
+    int64_t *root, *parent, *action, *visits, *depth, *legal, *tried, *nchild, *child;
+    double *total, *vmax, *prior_a, *svec, *reward;
+    uint8_t* done;
+    float* rows;                /* [cap][row_w] observation row of every node */
+} mctsq_forest;
+
+/* cur[k] (k_lo <= k < k_hi) = the leaf of this iteration (new node, or the terminal / depth-limit node selection stopped
+ * at).  slot_node[s] = id of the s-th new node; its observation is also written to slot s of `stage`, three blocks
+ * price [stage_cap][P] | process [stage_cap][6L] | gas [stage_cap][6] (the input layout of mctsq_q_forward).  Returns
+ * the number of new nodes, or -1 - (count of failed environment steps). */
+int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, double c_base, double c_init,
+                              uint64_t seed, uint64_t iteration, int64_t k_lo, int64_t k_hi, double noise_sigma,
+                              int64_t* cur, int64_t* slot_node, float* stage, int64_t stage_cap, int64_t* treedepth);
+/* vmax_out [n_new], prior_out [n_new][n_act]: the network outputs for the slots; then backup from cur[k]. */
+void mctsq_lockstep_backup(mctsq_forest* f, int64_t k_lo, int64_t k_hi, const int64_t* cur, const int64_t* slot_node,
+                           int64_t n_new, const float* vmax_out, const float* prior_out, int64_t n_act);
+/* the uniform in [0, 1) of (seed, iteration, k, stream): stream 0 = action choice, 1 / 2 = the Gaussian index noise */
+double mctsq_lockstep_uniform(uint64_t seed, uint64_t iteration, uint64_t k, uint64_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,8 @@
  * against each other.  Built by mcts_q_amd/csrc/Makefile into mcts_q_amd/lib/libmctsq_tree.so (gcc, no GPU code). */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "../../include/mctsq_tree.h"
 
 #define N_ACT 5
@@ -62,6 +64,54 @@ void mctsq_tree_backup(int64_t K, const int64_t* leaf, const double* vmax, const
     }
 }
 
+/* The two wide per-node arrays (observation row, state vector: ~1 KB per node together) are compacted through a
+ * grow-only scratch buffer in two parallel passes (gather the kept records, copy them back), since an in-place move is
+ * only safe in ascending order, i.e. serial.  `old_of` (n int64 scratch) receives the kept old ids in order.  The
+ * scratch buffer is shared by all forests of the process: calls must not overlap (the search driver is single-threaded). */
+static char* g_wide = NULL;
+static size_t g_wide_bytes = 0;
+
+static void compact_wide(int64_t n, int64_t m, const int64_t* newid, int64_t* old_of, float* rows, int64_t row_w,
+                         double* svec, int64_t D) {
+    int64_t first = m;                                   /* nodes before the first moved one stay where they are */
+    for (int64_t i = 0; i < n; ++i)
+        if (newid[i] >= 0) {
+            old_of[newid[i]] = i;
+            if (newid[i] != i && newid[i] < first) first = newid[i];
+        }
+    const int64_t moved = m - first;
+    if (moved <= 0) return;
+    const size_t rb = sizeof(float) * (size_t)row_w, sb = sizeof(double) * (size_t)D, rec = rb + sb;
+    if ((size_t)moved * rec > g_wide_bytes) {
+        free(g_wide);
+        g_wide_bytes = (size_t)moved * rec * 2;
+        g_wide = (char*)malloc(g_wide_bytes);
+        if (!g_wide) {                                   /* no scratch: the serial ascending move */
+            g_wide_bytes = 0;
+            for (int64_t j = first; j < m; ++j) {
+                memmove(rows + j * row_w, rows + old_of[j] * row_w, rb);
+                memmove(svec + j * D, svec + old_of[j] * D, sb);
+            }
+            return;
+        }
+    }
+#pragma omp parallel if (moved >= 2048)
+    {
+#pragma omp for schedule(static)
+        for (int64_t j = first; j < m; ++j) {
+            char* t = g_wide + (size_t)(j - first) * rec;
+            memcpy(t, rows + old_of[j] * row_w, rb);
+            memcpy(t + rb, svec + old_of[j] * D, sb);
+        }
+#pragma omp for schedule(static)
+        for (int64_t j = first; j < m; ++j) {
+            const char* t = g_wide + (size_t)(j - first) * rec;
+            memcpy(rows + j * row_w, t, rb);
+            memcpy(svec + j * D, t + rb, sb);
+        }
+    }
+}
+
 /* Sub-tree reuse (mctsq_config_mcts_per.py:153-167, 236-247): keep only the nodes under keep_roots[k] (>= 0), compact
  * every per-node array in place in ascending id order (children are always created after their parents, so the
  * order -- and with it every id the numpy path would assign -- is preserved), re-root the kept trees at depth 0.
@@ -96,11 +146,8 @@ int64_t mctsq_tree_retain(int64_t K, int64_t n, const int64_t* keep_roots, int64
             const int64_t c = child[i * N_ACT + a];
             child[j * N_ACT + a] = c >= 0 ? newid[c] : -1;
         }
-        if (j != i) {
-            for (int64_t c = 0; c < row_w; ++c) rows[j * row_w + c] = rows[i * row_w + c];
-            for (int64_t c = 0; c < D; ++c) svec[j * D + c] = svec[i * D + c];
-        }
     }
+    compact_wide(n, m, newid, rel, rows, row_w, svec, D);
     for (int64_t k = 0; k < K; ++k) {
         new_roots[k] = keep_roots[k] >= 0 ? newid[keep_roots[k]] : -1;
         if (new_roots[k] >= 0) parent[new_roots[k]] = -1;      /* detach from the previous root (:162) */

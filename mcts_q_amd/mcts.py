@@ -71,6 +71,74 @@ def _device_evaluator(policy_net):
     return evaluate
 
 
+class DeviceLeafEvaluator:
+    """Leaf evaluation for the C lock-step driver (treesearch.LockstepMCTS._search_fast): `halves` staging areas of
+    `cap` leaves each in pinned host memory, laid out as the forward kernel's three inputs (price [cap,25] | process
+    [cap,60] | gas [cap,6]), which the driver fills in place.  launch(h, n) enqueues ONE copy of the area to the device
+    and ONE forward launch whose epilogue stores max_a Q and softmax(Q) straight into pinned host memory (no D2H copy
+    of its own), then records an event; wait(h) blocks on that event.  With zero_copy the kernel reads the pinned
+    staging area itself and the H2D copy goes away too.  Called as a function it is the plain evaluator
+    (rows -> vmax, prior) the generic driver uses."""
+
+    def __init__(self, policy_net, cap: int, halves: int = 2, zero_copy: bool = False):
+        import ctypes as C
+        from ._lib import lib, ptr
+        self._C, self._lib, self._ptr = C, lib, ptr
+        self.net = policy_net.qnet if hasattr(policy_net, "qnet") else policy_net    # DeviceQNet
+        self.plain = _device_evaluator(policy_net)
+        self.cap, self.halves, self.zero_copy = int(cap), int(halves), bool(zero_copy)
+        net, dev = self.net, self.net.device
+        A = net.spec.action_dim
+        self.n_act = A
+        cap = self.cap
+        self._hin = [torch.zeros(cap * 91, dtype=torch.float32, pin_memory=True) for _ in range(halves)]
+        self._din = [torch.zeros(cap * 91, dtype=torch.float32, device=dev) for _ in range(halves)]
+        self._hout = [torch.zeros(cap * (1 + A), dtype=torch.float32, pin_memory=True) for _ in range(halves)]
+        self._q = [torch.empty(cap, A, dtype=torch.float32, device=dev) for _ in range(halves)]
+        self._arg = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(halves)]
+        self._ev = [torch.cuda.Event() for _ in range(halves)]
+        nbytes = lib.check(lib.mctsq_q_forward_workspace_bytes(C.byref(net.desc), cap))
+        self._ws = [torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev) for _ in range(halves)]
+        self._args = None
+
+    def __call__(self, rows):
+        return self.plain(rows)
+
+    def begin(self):
+        """Bind the pointers of one search: the weights do not change inside predict()."""
+        net, C, ptr, cap = self.net, self._C, self._ptr, self.cap
+        self._stream = torch.cuda.current_stream(net.device)
+        st = self._stream.cuda_stream
+        prep = ptr(net._prepared())
+        self._args = []
+        for h in range(self.halves):
+            src = self._hin[h] if self.zero_copy else self._din[h]
+            base = src.data_ptr()
+            self._args.append((C.byref(net.desc), ptr(net.flat), prep, base, base + 4 * cap * 25, base + 4 * cap * 85,
+                               ptr(self._q[h]), self._hout[h].data_ptr(), ptr(self._arg[h]),
+                               self._hout[h].data_ptr() + 4 * cap, ptr(self._ws[h]), self._ws[h].numel(), st, None))
+
+    def stage_ptr(self, h):
+        return self._hin[h].data_ptr()
+
+    def vmax_ptr(self, h):
+        return self._hout[h].data_ptr()
+
+    def prior_ptr(self, h):
+        return self._hout[h].data_ptr() + 4 * self.cap
+
+    def launch(self, h, n):
+        a = self._args[h]
+        if not self.zero_copy:
+            self._din[h].copy_(self._hin[h], non_blocking=True)
+        self._lib.check(self._lib.mctsq_q_forward_prepared(a[0], a[1], a[2], a[3], a[4], a[5], n, a[6], a[7], a[8], a[9],
+                                                           a[10], a[11], a[12], a[13]))
+        self._ev[h].record(self._stream)
+
+    def wait(self, h):
+        self._ev[h].synchronize()
+
+
 class MCTSQ:
     """Drop-in for the reference's MCTSQ (mcts_per.py:33-466): one environment, one tree."""
 
@@ -201,7 +269,7 @@ class LockstepAgent:
 
     def __init__(self, envs, dqn: DQNModel, iterations: int, maximum_depth: int, c_base: float, c_init: float,
                  tau: float = 0.005, tree_remain_interval: int = 10, seed: int = 0, updates_per_step: int = 1,
-                 batch_env=None, n_trees: int | None = None):
+                 batch_env=None, n_trees: int | None = None, zero_copy: bool = False):
         """envs: K environments with the `_per` protocol, OR batch_env (+ n_trees): one vectorised environment
         with the batched protocol of treesearch.LockstepMCTS (reset(seeds), observe, step_batch)."""
         self.dqn, self.batch_env = dqn, batch_env
@@ -209,8 +277,12 @@ class LockstepAgent:
         self.step_count, self.leaf_evals = 0, 0
         if batch_env is not None:
             self.K = int(n_trees)
-            self.search = LockstepMCTS(self.K, _device_evaluator(dqn.policy_net), iterations, maximum_depth, c_base,
-                                       c_init, batch_env=batch_env, seed=seed)
+            if getattr(batch_env, "c_env", None):
+                halves = 2 if self.K >= 64 else 1
+                ev = DeviceLeafEvaluator(dqn.policy_net, -(-self.K // halves), halves, zero_copy=zero_copy)
+            else:
+                ev = _device_evaluator(dqn.policy_net)
+            self.search = LockstepMCTS(self.K, ev, iterations, maximum_depth, c_base, c_init, batch_env=batch_env, seed=seed)
             self._episode = np.arange(self.K, dtype=np.int64)
             self.states = batch_env.reset(self._episode + seed * 1000003)
             self.rows, _ = batch_env.observe(self.states)

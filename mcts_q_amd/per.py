@@ -79,8 +79,13 @@ class DevicePER:
             small = np.empty((3, K), dtype=np.float32)
             small[0] = actions; small[1] = rewards; small[2] = dones
             sm = torch.from_numpy(small).to(d)
+            same = next_rows is rows or (isinstance(rows, np.ndarray) and isinstance(next_rows, np.ndarray) and
+                                         rows.shape == next_rows.shape and rows.dtype == next_rows.dtype and
+                                         rows.__array_interface__["data"][0] == next_rows.__array_interface__["data"][0] and
+                                         rows.strides == next_rows.strides)
             rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(d)
-            next_rows = torch.from_numpy(np.ascontiguousarray(next_rows, dtype=np.float32)).to(d)
+            # the expansion transitions of the tree search carry the same row as state and next state (mcts_per.py:337-340)
+            next_rows = rows if same else torch.from_numpy(np.ascontiguousarray(next_rows, dtype=np.float32)).to(d)
             actions, rewards, dones = sm[0].to(torch.int32), sm[1], sm[2]
         else:
             rows = torch.as_tensor(rows, dtype=torch.float32, device=d)

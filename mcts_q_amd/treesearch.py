@@ -22,13 +22,15 @@ returns the first maximum in that order (mcts_per.py:308, 553).
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 import random
+import time
 
 import numpy as np
 
-from .leafbatch import ROW, obs_to_row
+from .leafbatch import N_PRICE, ROW, obs_to_row
 
 N_ACT = 5
 # MCTSNode.get_legal_actions (mcts_per.py:524-546) as bit masks over actions 0..4
@@ -50,6 +52,71 @@ def legal_mask(meth_state) -> int:
 _TREE_LIB = None
 
 
+def _mix64(z):
+    z = z + np.uint64(0x9E3779B97F4A7C15)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def lockstep_uniform(seed: int, iteration: int, k, stream: int):
+    """mctsq_lockstep_uniform (csrc_host/lockstep.c) for an array of tree indices: the counter-based uniform in
+    [0, 1) of (seed, iteration, tree, stream).  Both drivers (numpy and C) draw from it, so they build the same trees."""
+    with np.errstate(over="ignore"):
+        it = np.array([iteration], dtype=np.uint64) * np.uint64(0xD1342543DE82EF95) + np.uint64(stream)
+        x = _mix64(np.array([seed], dtype=np.uint64) ^ _mix64(it) ^
+                   _mix64(np.asarray(k, dtype=np.uint64) + np.uint64(0x632BE59BD9B4E019)))
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+class Forest(ctypes.Structure):
+    """mctsq_forest (include/mctsq_tree.h)."""
+    _fields_ = ([(k, ctypes.c_int64) for k in ("K", "cap", "n", "D", "row_w")] +
+                [(k, ctypes.c_void_p) for k in ("root", "parent", "action", "visits", "depth", "legal", "tried", "nchild",
+                                                "child", "total", "vmax", "prior_a", "svec", "reward", "done", "rows")])
+
+
+class HostStagedEvaluator:
+    """Adapter giving a plain evaluate(rows) -> (vmax, prior) function the staged interface the C driver feeds
+    (stage_ptr / launch / wait / vmax_ptr / prior_ptr, `halves` independent staging areas of `cap` slots each).
+    mcts.DeviceLeafEvaluator is the device implementation of the same interface."""
+
+    def __init__(self, evaluate, cap: int, row_w: int = ROW, n_act: int = N_ACT, halves: int = 2):
+        self.evaluate, self.cap, self.row_w, self.n_act, self.halves = evaluate, int(cap), int(row_w), int(n_act), halves
+        self._stage = [np.zeros(self.cap * self.row_w, dtype=np.float32) for _ in range(halves)]
+        self._vmax = [np.zeros(self.cap, dtype=np.float32) for _ in range(halves)]
+        self._prior = [np.zeros((self.cap, self.n_act), dtype=np.float32) for _ in range(halves)]
+
+    def __call__(self, rows):
+        return self.evaluate(rows)
+
+    def begin(self):
+        pass
+
+    def stage_ptr(self, h):
+        return self._stage[h].ctypes.data
+
+    def vmax_ptr(self, h):
+        return self._vmax[h].ctypes.data
+
+    def prior_ptr(self, h):
+        return self._prior[h].ctypes.data
+
+    def launch(self, h, n):
+        cap, w = self.cap, self.row_w
+        st = self._stage[h]
+        P, G = N_PRICE, 6
+        L6 = w - P - G
+        rows = np.concatenate([st[:cap * P].reshape(cap, P)[:n], st[cap * P:cap * (P + L6)].reshape(cap, L6)[:n],
+                               st[cap * (P + L6):].reshape(cap, G)[:n]], axis=1)
+        vmax, prior = self.evaluate(rows)
+        self._vmax[h][:n] = np.asarray(vmax, dtype=np.float32)
+        self._prior[h][:n] = np.asarray(prior, dtype=np.float32)
+
+    def wait(self, h):
+        pass
+
+
 def _tree_lib():
     """libmctsq_tree.so (mcts_q_amd/csrc_host/tree_ops.c): selection and backup over all trees in C, spread over
     the host cores.  Raises if the library was not built (python -c 'import __graft_entry__ as g; g.build()')."""
@@ -67,6 +134,13 @@ def _tree_lib():
         L.mctsq_tree_backup.restype = None
         L.mctsq_tree_retain.argtypes = [I64, I64] + [P] * 15 + [I64, P, I64, P, P]
         L.mctsq_tree_retain.restype = I64
+        U64 = ctypes.c_uint64
+        L.mctsq_lockstep_expand.argtypes = [ctypes.POINTER(Forest), P, I64, F64, F64, U64, U64, I64, I64, F64, P, P, P, I64, P]
+        L.mctsq_lockstep_expand.restype = I64
+        L.mctsq_lockstep_backup.argtypes = [ctypes.POINTER(Forest), I64, I64, P, P, I64, P, P, I64]
+        L.mctsq_lockstep_backup.restype = None
+        L.mctsq_lockstep_uniform.argtypes = [U64, U64, U64, U64]
+        L.mctsq_lockstep_uniform.restype = F64
         _TREE_LIB = L
     return _TREE_LIB
 
@@ -109,12 +183,23 @@ class LockstepMCTS:
         assert len(self.rngs) == self.K
         self.batch_env = batch_env
         self.D = int(batch_env.state_dim) if batch_env is not None else 0
-        self.np_rng = np.random.default_rng(seed)
+        self.seed, self.iter_count = int(seed) & (2 ** 64 - 1), 0
+        self.prof = None
+        self._compact = False       # True right after _retain: every stored node hangs under a current root
+        # C driver: the whole iteration (selection, action choice, environment step, node creation / backup) in one
+        # call per block of trees, when the environment is the C one (ptgenv.PtGBatchEnv exposes its handle as c_env)
+        self.fast = bool(self.native and batch_env is not None and getattr(batch_env, "c_env", None))
         self.root = np.full(self.K, -1, dtype=np.int64)
         self.treedepth = np.zeros(self.K, dtype=np.int64)
         self._alloc(0)
         self.n = 0
         self._logtab = []
+        if self.fast:
+            if int(batch_env.row_width) != ROW:
+                raise ValueError(f"the leaf batch layout needs {ROW}-scalar observations, the environment has {batch_env.row_width}")
+            if not hasattr(evaluate, "launch"):
+                self.evaluate = HostStagedEvaluator(evaluate, -(-self.K // 2) if self.K >= 64 else self.K, ROW, N_ACT,
+                                                    2 if self.K >= 64 else 1)
 
     # ---- storage ------------------------------------------------------------------------------
     def _alloc(self, cap):
@@ -131,10 +216,25 @@ class LockstepMCTS:
         self.child = np.full((cap, N_ACT), -1, dtype=np.int64)      # creation order
         self.vmax = np.zeros(cap, dtype=np.float64)
         self.prior_a = np.zeros(cap, dtype=np.float64)
-        self.rows = np.zeros((cap, ROW), dtype=np.float32)
+        self.rows = self._alloc_rows(cap)
         self.svec = np.zeros((cap, self.D), dtype=np.float64)       # batched-environment mode: state vectors
+        self.reward = np.zeros(cap, dtype=np.float64)               # reward of the transition that created the node
+        self._forest = None
         self.state_c = [None] * cap
         self.extra = [None] * cap           # (meth_state_tr, el_price_tr, pot_reward_tr) of mcts_per.py:351-353
+
+    def _alloc_rows(self, cap):
+        """Observation rows; with the C driver on a GPU host they live in pinned memory, so the replay push of a whole
+        search's expansions is one direct DMA."""
+        if getattr(self, "fast", False) and cap:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    self._rows_pin = torch.zeros((cap, ROW), dtype=torch.float32, pin_memory=True)
+                    return self._rows_pin.numpy()
+            except ImportError:
+                pass
+        return np.zeros((cap, ROW), dtype=np.float32)
 
     def _grow(self, need):
         if need <= self.cap:
@@ -144,7 +244,7 @@ class LockstepMCTS:
         self._alloc(cap)
         n = old["n"] if "n" in old else 0
         for k in ("parent", "action", "visits", "total", "depth", "done", "legal", "tried", "nchild", "child",
-                  "vmax", "prior_a", "rows", "svec"):
+                  "vmax", "prior_a", "rows", "svec", "reward"):
             getattr(self, k)[:n] = old[k][:n]
         self.state_c[:n] = old["state_c"][:n]
         self.extra[:n] = old["extra"][:n]
@@ -193,18 +293,21 @@ class LockstepMCTS:
         return np.asarray(self._logtab, dtype=np.float64)[tv]
 
     def _evaluate_nodes(self, ids):
-        if len(ids) == 0:
+        """ids: an index array, or a slice (all nodes: no gather copy of the rows)."""
+        m = (ids.stop - ids.start) if isinstance(ids, slice) else len(ids)
+        if m == 0:
             return
         vmax, prior = self.evaluate(self.rows[ids])
         self.vmax[ids] = np.asarray(vmax, dtype=np.float32).astype(np.float64)          # q.max().item() (:370)
         prior = np.asarray(prior, dtype=np.float32)
         act = np.where(self.action[ids] >= 0, self.action[ids], 0)
-        self.prior_a[ids] = prior[np.arange(len(ids)), act].astype(np.float64)          # prior[idx, action].item() (:296)
+        self.prior_a[ids] = prior[np.arange(m), act].astype(np.float64)                 # prior[idx, action].item() (:296)
 
     # ---- sub-tree reuse (mcts_per.py:153-167, 236-247) -----------------------------------------
     def _retain(self, keep_roots):
         """Compact the arrays to the sub-trees under keep_roots[i] (>= 0), re-rooted at depth 0."""
         K = self.K
+        self._compact = True
         if self.n == 0 or not (keep_roots >= 0).any():
             self.n = 0
             return np.full(K, -1, dtype=np.int64)
@@ -305,7 +408,9 @@ class LockstepMCTS:
             keep[:] = -1
         else:
             keep[~np.asarray(reuse, dtype=bool)] = -1
-        self.root = self._retain(keep)
+        if not (self._compact and np.array_equal(keep, self.root)):    # advance() already left exactly these sub-trees
+            self.root = self._retain(keep)
+        self._compact = False
         fresh = np.nonzero(self.root < 0)[0]
         if len(fresh) and benv is not None:
             sv = np.asarray(state_cs, dtype=np.float64)[fresh]
@@ -314,9 +419,16 @@ class LockstepMCTS:
         elif len(fresh):
             ids = self._new_nodes([state_cs[i] for i in fresh], -1, -1, False, 0)
             self.root[fresh] = ids
-        self._evaluate_nodes(np.arange(self.n))        # fresh roots + retained sub-trees under the current weights
+        self._evaluate_nodes(slice(0, self.n))         # fresh roots + retained sub-trees under the current weights
         trees = np.arange(K)
         maxd = self.maximum_depth
+        if self.fast:
+            n0 = self.n
+            self._search_fast(maxd)
+            if train and push_rows is not None and self.n > n0:       # the expansions of this search, in creation order
+                new = slice(n0, self.n)
+                push_rows(self.rows[new], self.action[new], self.reward[new], self.rows[new], self.done[new])
+            return self._most_visited(trees)
         for _ in range(self.iterations):
             # -- selection (:266-308)
             if self.native:
@@ -333,9 +445,16 @@ class LockstepMCTS:
             if len(exp) and benv is not None:
                 par = cur[exp]
                 mask = self.legal[par] & ~self.tried[par] & _ALL
-                k = np.minimum((self.np_rng.random(len(exp)) * _NBITS[mask]).astype(np.int64), _NBITS[mask] - 1)
+                u = lockstep_uniform(self.seed, self.iter_count, exp, 0)
+                k = np.minimum((u * _NBITS[mask]).astype(np.int64), _NBITS[mask] - 1)
                 acts = _KTH[mask, k]
-                nsv, rows, rew, term, trunc, meth = benv.step_batch(self.svec[par], acts)
+                sigma = float(getattr(benv, "noise", 0.0) or 0.0)
+                if hasattr(benv, "noise"):                # index noise of mode changes from the same counter-based stream
+                    u1, u2 = (lockstep_uniform(self.seed, self.iter_count, exp, q) for q in (1, 2))
+                    nz = sigma * np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(6.283185307179586 * u2) if sigma else np.zeros(len(exp))
+                    nsv, rows, rew, term, trunc, meth = benv.step_batch(self.svec[par], acts, noise=nz)
+                else:
+                    nsv, rows, rew, term, trunc, meth = benv.step_batch(self.svec[par], acts)
                 if train and push_rows is not None:
                     push_rows(rows, acts, rew, rows, term)                # state == next state here (:337-340)
                 ids = self._new_nodes_batch(nsv, rows, meth, par, acts, np.asarray(term, dtype=bool) | np.asarray(trunc, dtype=bool),
@@ -383,6 +502,81 @@ class LockstepMCTS:
                     self.total[nl] += value[live]
                     node[live] = self.parent[nl]
                     live = node >= 0
+            self.iter_count += 1
+        return self._most_visited(trees)
+
+    def _forest_struct(self):
+        f = self._forest
+        if f is None:
+            f = self._forest = Forest()
+            f.K, f.cap, f.D, f.row_w = self.K, self.cap, self.D, self.rows.shape[1]
+            for k in ("parent", "action", "visits", "depth", "legal", "tried", "nchild", "child", "total", "vmax",
+                      "prior_a", "svec", "reward", "done", "rows"):
+                setattr(f, k, getattr(self, k).ctypes.data)
+        f.n, f.root = self.n, self.root.ctypes.data            # predict() replaces the root array
+        return f
+
+    def _search_fast(self, maxd):
+        """The iterations of predict() through the C driver, the trees in `halves` blocks that alternate between the
+        host (selection / environment / backup) and the device (leaf batch): while one block's leaves are being
+        evaluated the other block is advanced.  Per tree the order select -> expand -> evaluate -> backup and every
+        random draw are those of the numpy path."""
+        K, ev, L = self.K, self.evaluate, self._lib
+        self._grow(self.n + K * self.iterations)
+        f = self._forest_struct()
+        fp = ctypes.byref(f)
+        nh = ev.halves if K >= 2 * 32 else 1
+        bounds = [(h * K // nh, (h + 1) * K // nh) for h in range(nh)]
+        if max(hi - lo for lo, hi in bounds) > ev.cap:
+            raise ValueError("leaf staging area smaller than a block of trees")
+        cur = np.empty(K, dtype=np.int64)
+        slots = [np.empty(hi - lo, dtype=np.int64) for lo, hi in bounds]
+        pend = [None] * nh
+        env, sigma = self.batch_env.c_env, float(self.batch_env.noise)
+        cb, ci, A = float(self.c_base), float(self.c_init), N_ACT
+        curp, tdp = cur.ctypes.data, self.treedepth.ctypes.data
+        ev.begin()
+
+        prof = self.prof                     # optional wall-clock split {wait, backup, expand, launch} (tools/tree_bench.py)
+        clock = time.perf_counter
+
+        def finish(h):
+            n_new = pend[h]
+            t0 = clock() if prof is not None else 0.0
+            if n_new:
+                ev.wait(h)
+            t1 = clock() if prof is not None else 0.0
+            lo, hi = bounds[h]
+            L.mctsq_lockstep_backup(fp, lo, hi, curp, slots[h].ctypes.data, n_new, ev.vmax_ptr(h), ev.prior_ptr(h), A)
+            pend[h] = None
+            if prof is not None:
+                prof["wait"] += t1 - t0
+                prof["backup"] += clock() - t1
+
+        for _ in range(self.iterations):
+            for h, (lo, hi) in enumerate(bounds):
+                if pend[h] is not None:
+                    finish(h)
+                t0 = clock() if prof is not None else 0.0
+                n_new = L.mctsq_lockstep_expand(fp, env, maxd, cb, ci, self.seed, self.iter_count, lo, hi, sigma, curp,
+                                                slots[h].ctypes.data, ev.stage_ptr(h), ev.cap, tdp)
+                if n_new < 0:
+                    raise IndexError(f"environment step failed for {-1 - n_new} states (clock outside the price tables, "
+                                     "or staging / node capacity exceeded)")
+                t1 = clock() if prof is not None else 0.0
+                if n_new:
+                    ev.launch(h, n_new)
+                pend[h] = n_new
+                if prof is not None:
+                    prof["expand"] += t1 - t0
+                    prof["launch"] += clock() - t1
+            self.iter_count += 1
+        for h in range(nh):
+            if pend[h] is not None:
+                finish(h)
+        self.n = int(f.n)
+
+    def _most_visited(self, trees):
         # -- most visited child, first maximum in creation order (:256, 553)
         if (self.nchild[self.root] == 0).any():
             raise ValueError("most_visited_child of a root without children (terminal root or iterations == 0)")

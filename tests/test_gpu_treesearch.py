@@ -123,3 +123,56 @@ def test_lockstep_agent_batched_environment():
             losses.append(float(loss))
     assert 7 * K < len(dqn.replay_buffer) <= 7 * K * 11
     assert losses and np.isfinite(losses).all()
+
+
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_c_driver_with_the_device_evaluator_equals_the_numpy_driver(zero_copy):
+    """SURVEY 8f-2 on the device: the C lock-step driver over the vectorised PtG environment, leaves staged in pinned
+    memory and evaluated by one forward launch per block of trees (outputs written to pinned host memory by the kernel),
+    the two blocks alternating between host and device - against the numpy driver calling the plain device evaluator
+    with the same counter-based draws.  The forward is row-wise, so trees, visit counts, values and replay pushes are
+    identical bit for bit; the agent-level loop (search, environment step, replay, learner step) runs on top of it."""
+    from mcts_q_amd.dqn import DQNModel
+    from mcts_q_amd.mcts import DeviceLeafEvaluator, LockstepAgent
+    from mcts_q_amd.ptgenv import PtGBatchEnv
+    from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
+    from mcts_q_amd.treesearch import LockstepMCTS
+    kw = synthetic_ptg_kwargs(5, scale=0.2)
+    dqn = DQNModel(1, 6, 2, 5, 64, 2, 128, buffer_capacity=20000, batch_size=64, gamma=0.99, lr=1e-3,
+                   price_encoder_type="gru", process_encoder_type="gru", gas_eua_encoder_type="gru", learning_starts=64,
+                   seed=11)
+    K, iters = 96, 12
+    runs = []
+    for fast in (True, False):
+        env = PtGBatchEnv(kw, seed=1)
+        ev = DeviceLeafEvaluator(dqn.policy_net, K // 2, 2, zero_copy=zero_copy)
+        drv = LockstepMCTS(K, ev, iters, 8, 19652, 1.25, batch_env=env, seed=3)
+        assert drv.fast
+        drv.fast = fast
+        states = env.reset(np.arange(K))
+        warm = np.random.RandomState(0)
+        for _ in range(4):
+            states = env.step_batch(states, warm.randint(0, 5, K), noise=np.zeros(K))[0]
+        rec = []
+        for step in range(3):
+            pushed = []
+            a = drv.predict(states, train=True, reuse=np.ones(K, dtype=bool),
+                            push_rows=lambda *x: pushed.append([np.array(v, dtype=np.float64) for v in x]))
+            n = drv.n
+            rec.append([a.copy(), np.array(n), drv.visits[:n].copy(), drv.total[:n].copy(), drv.parent[:n].copy(),
+                        drv.vmax[:n].copy(), drv.prior_a[:n].copy()] +
+                       [np.concatenate([p[q] for p in pushed]) for q in range(5)])
+            states = env.step_batch(states, a, noise=np.zeros(K))[0]
+            drv.advance(a, keep=np.ones(K, dtype=bool))
+        runs.append(rec)
+    for x, y in zip(*runs):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)
+    env = PtGBatchEnv(kw, seed=1)
+    agent = LockstepAgent(None, dqn, iterations=iters, maximum_depth=8, c_base=19652, c_init=1.25, batch_env=env,
+                          n_trees=K, zero_copy=zero_copy)
+    loss = None
+    for _ in range(3):
+        actions, rewards, loss = agent.step()
+    assert len(dqn.replay_buffer) >= 3 * K * (iters + 1) - 3 * K and loss is not None and np.isfinite(float(loss))
+    assert agent.leaf_evals >= 3 * K * iters

@@ -128,13 +128,17 @@ class _PerAdapter:
 
 
 class _UniformChoice:
-    """random.choice driven by the numpy stream the batched driver draws from (one uniform per expansion)."""
+    """random.choice driven by the counter-based stream the batched drivers draw from (tree 0, one iteration per
+    call: in the test below every iteration expands)."""
 
     def __init__(self, seed):
-        self.g = np.random.default_rng(seed)
+        self.seed, self.it = seed, 0
 
     def choice(self, seq):
-        return seq[min(int(self.g.random(1)[0] * len(seq)), len(seq) - 1)]
+        from mcts_q_amd.treesearch import lockstep_uniform
+        u = float(lockstep_uniform(self.seed, self.it, [0], 0)[0])
+        self.it += 1
+        return seq[min(int(u * len(seq)), len(seq) - 1)]
 
 
 def test_batched_environment_mode_equals_reference_search():
@@ -207,3 +211,51 @@ def test_native_select_and_backup_equal_numpy_path(K, iters, horizon):
         assert x[1] == y[1]
         for u, v in zip(x, y):
             assert np.array_equal(u, v)
+
+
+def _hash_eval(rows):
+    """Deterministic stand-in for the network, row-wise (so batch composition does not matter)."""
+    r = np.asarray(rows, dtype=np.float64)
+    q = np.stack([np.sin(r @ (np.arange(1, r.shape[1] + 1) * (0.37 + 0.11 * a)) + a) for a in range(5)], axis=1)
+    e = np.exp(q - q.max(1, keepdims=True))
+    return q.max(1).astype(np.float32), (e / e.sum(1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("K,iters,noise", [(1, 30, 0.0), (37, 20, 10.0), (300, 12, 10.0)])
+def test_c_lockstep_driver_equals_numpy_driver_on_the_ptg_environment(K, iters, noise):
+    """csrc_host/lockstep.c (one call per iteration and block of trees, blocks alternating as they would around device
+    launches) against the numpy driver with the same counter-based draws: identical trees, actions, replay pushes, over
+    environment steps with sub-tree reuse; the C uniform equals its numpy statement."""
+    from mcts_q_amd.ptgenv import PtGBatchEnv
+    from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
+    from mcts_q_amd.treesearch import _tree_lib, lockstep_uniform
+    kw = synthetic_ptg_kwargs(2, scale=0.2, env_values=dict(noise=noise))
+    L = _tree_lib()
+    for it, k, s in ((0, 0, 0), (7, 299, 1), (123456, 5, 2)):
+        assert L.mctsq_lockstep_uniform(99, it, k, s) == lockstep_uniform(99, it, [k], s)[0]
+    runs = []
+    for fast in (True, False):
+        env = PtGBatchEnv(kw, seed=1)
+        drv = LockstepMCTS(K, _hash_eval, iters, 6, 19652, 1.25, batch_env=env, seed=99)
+        assert drv.fast
+        drv.fast = fast
+        states = env.reset(np.arange(K))
+        warm = np.random.RandomState(0)
+        for _ in range(5):                                            # leave the initial cooldown state
+            states = env.step_batch(states, warm.randint(0, 5, K), noise=np.zeros(K))[0]
+        rec = []
+        for step in range(3):
+            pushed = []
+            a = drv.predict(states, train=True, reuse=np.ones(K, dtype=bool), push_rows=lambda *x: pushed.append([np.array(v) for v in x]))
+            push = [np.concatenate([p[q] for p in pushed]) for q in range(5)]
+            n = drv.n
+            rec.append([a.copy(), np.array(n), drv.visits[:n].copy(), drv.total[:n].copy(), drv.parent[:n].copy(),
+                        drv.action[:n].copy(), drv.svec[:n].copy(), drv.rows[:n].copy(), drv.treedepth.copy(),
+                        drv.done[:n].copy()] + [np.asarray(p, dtype=np.float64) for p in push])
+            states = env.step_batch(states, a, noise=np.zeros(K))[0]
+            drv.advance(a, keep=np.ones(K, dtype=bool))
+        runs.append(rec)
+    for x, y in zip(*runs):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)
+    assert (runs[0][0][2][:1] >= 1).all() and int(runs[0][2][1]) > K
