@@ -260,7 +260,7 @@ int mctsq_per_sample_batch(const uint64_t* d_tree, const double* d_prio, int64_t
  * wins); d_idx LOGICAL int64 [B], d_newprio fp32 [B].  d_stamp: int32 [capacity] scratch owned by
  * the buffer, all -1 on entry (the call leaves it all -1 again).  Indices outside [0, size) name no stored
  * transition and are ignored (the reference raises IndexError; host-side callers check before calling).
- * One launch for B <= 4096. */
+ * One launch for B <= 2048 (exact last-writer table in LDS); marking + apply launches above. */
 int mctsq_per_update(uint64_t* d_tree, double* d_prio, int32_t* d_stamp, int64_t capacity,
                      int64_t head, int64_t size, const int64_t* d_idx, const float* d_newprio,
                      int64_t B, double alpha, int64_t mass_capacity, void* stream);
