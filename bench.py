@@ -354,21 +354,22 @@ def main():
         if world > 1:
             train_weak = run_train(args.train_batch * world, "weak (global batch = %d x ranks)" % args.train_batch)
 
-    # --- lock-step MCTS in situ (config 5 shape per rank: `trees` trees x 50 iterations, one leaf batch per
-    # iteration, vectorised synthetic environment; search only, weights fixed) -----------------------------
+    # --- lock-step MCTS in situ (config 5 shape per rank: `trees` trees x 50 iterations): the C search iteration over
+    # the vectorised PtG environment (real step arithmetic on synthetic tables of the real sizes), leaves staged in
+    # pinned memory, ONE forward launch per block of trees and iteration, two blocks alternating between host and
+    # device; search only, weights fixed -------------------------------------------------------------------
     trees = None
     if not args.no_trees:
-        from mcts_q_amd.leafbatch import split_rows
-        from mcts_q_amd.synthetic_env import FakeBatchEnv
+        from mcts_q_amd.mcts import DeviceLeafEvaluator
+        from mcts_q_amd.ptgenv import PtGBatchEnv
+        from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
         from mcts_q_amd.treesearch import LockstepMCTS
 
-        def evaluate(rows):
-            o = net(*split_rows(torch.from_numpy(np.ascontiguousarray(rows)).to(dev, non_blocking=True)))
-            return o["vmax"].cpu().numpy(), o["prior"].cpu().numpy()
-
-        benv = FakeBatchEnv()
-        K, iters, tsteps = args.trees, 50, 3
-        drv = LockstepMCTS(K, evaluate, iters, 42, 19652, 1.25, batch_env=benv, seed=rank)
+        benv = PtGBatchEnv(synthetic_ptg_kwargs(0, scale=1.0, train_days=46, env_values=dict(eps_len_d=40)), seed=rank)
+        K, iters, tsteps = args.trees, 50, 5
+        halves = 2 if K >= 64 else 1
+        drv = LockstepMCTS(K, DeviceLeafEvaluator(net, -(-K // halves), halves, zero_copy=True), iters, 42, 19652, 1.25,
+                           batch_env=benv, seed=rank)
         st = benv.reset(np.arange(K) + 100000 * rank)
         a = drv.predict(st, train=False)                      # warm-up search
         barrier()
@@ -378,10 +379,11 @@ def main():
             a = drv.predict(st, train=False)
         barrier()
         swall = max_over_ranks(time.perf_counter() - t0)
-        trees = {"metric": "leaf evals/s inside the lock-step tree search (host tree logic + vectorised synthetic "
-                           "environment + one leaf batch per iteration)", "trees_per_gpu": K, "iterations": iters,
-                 "searches": tsteps, "s_per_search_of_all_trees": swall / tsteps,
-                 "value": world * tsteps * K * (iters + 1) / swall, "unit": "leaf evals/s", "scaling": "weak"}
+        trees = {"metric": "leaf evals/s inside the lock-step tree search (C search iteration + vectorised PtG environment "
+                           "step on the host, one leaf batch per block of trees and iteration on the device)",
+                 "trees_per_gpu": K, "iterations": iters, "searches": tsteps, "s_per_search_of_all_trees": swall / tsteps,
+                 "value": world * tsteps * K * (iters + 1) / swall, "unit": "leaf evals/s", "scaling": "weak",
+                 "with_learner_and_replay_in_the_loop": "tools/tree_bench.py 512 5 50 ptg0 (DESIGN.md section 7)"}
 
     if rank == 0:
         res = {

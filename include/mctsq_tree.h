@@ -113,6 +113,29 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
 /* vmax_out [n_new], prior_out [n_new][n_act]: the network outputs for the slots; then backup from cur[k]. */
 void mctsq_lockstep_backup(mctsq_forest* f, int64_t k_lo, int64_t k_hi, const int64_t* cur, const int64_t* slot_node,
                            int64_t n_new, const float* vmax_out, const float* prior_out, int64_t n_act);
+/* ---- all iterations of one search in ONE call: the loop over (iteration, block of trees) around expand / backup, with
+ * the leaf batches launched through function pointers the caller supplies (this library links no GPU runtime):
+ * `forward` = mctsq_q_forward_prepared (include/mctsq_hip.h), `event_record` / `event_sync` / `memcpy_async` =
+ * hipEventRecord / hipEventSynchronize / hipMemcpyAsync, or host functions of the same shape in tests.  Block h of
+ * `halves` (1..4) covers trees [h*K/halves, (h+1)*K/halves) and owns staging area, outputs, workspace and event h;
+ * while block h's leaves are on the device, the other blocks are advanced on the host.  cur, slots: K int64 of scratch each.  stage[h]: pinned host memory in
+ * the forward's input layout (three blocks of `cap` rows); dev_in[h]: device copy of it, or NULL to let the kernel
+ * read the pinned staging area itself; vmax[h] / prior[h]: host-visible outputs.  prof (NULL or 4 doubles) receives
+ * seconds spent waiting for the device, in backup, in expand, in launching.  Returns 0, or < 0: -1 - n for n failed
+ * environment steps / capacity, -1000 - rc for a failing forward / copy / event call. */
+typedef struct {
+    void *forward, *event_record, *event_sync, *memcpy_async;
+    const void *net, *params, *prep;
+    void* stream;
+    int64_t halves, cap, ws_bytes, n_act;
+    float *stage[4], *dev_in[4], *q[4], *vmax[4], *prior[4];
+    int32_t* argmax[4];
+    void *ws[4], *event[4];
+} mctsq_leaf_eval;
+int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, double c_base, double c_init,
+                              uint64_t seed, uint64_t iteration0, int64_t iterations, double noise_sigma,
+                              const mctsq_leaf_eval* ev, int64_t* cur, int64_t* slots, int64_t* treedepth,
+                              double* prof);
 /* the uniform in [0, 1) of (seed, iteration, k, stream): stream 0 = action choice, 1 / 2 = the Gaussian index noise */
 double mctsq_lockstep_uniform(uint64_t seed, uint64_t iteration, uint64_t k, uint64_t stream);
 

@@ -6,10 +6,25 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <time.h>
+#include <stdlib.h>
+#include <omp.h>
 #include "../../include/mctsq_tree.h"
 
 #define N_ACT 5
 static const int64_t LEGAL_OF_STATE[5] = {0x07, 0x07, 0x1B, 0x1B, 0x1B};     /* get_legal_actions (:524-546) */
+
+/* threads of the per-block loops: MCTSQ_TREE_THREADS if set (a block of a few hundred trees is ~10 us of work per
+ * thread, so the fork / join cost of a wide team can outweigh it), else OpenMP's own default */
+static int tree_threads(void) {
+    static int n = -1;
+    if (n < 0) {
+        const char* e = getenv("MCTSQ_TREE_THREADS");
+        n = e ? atoi(e) : 0;
+        if (n <= 0) n = omp_get_max_threads();
+    }
+    return n;
+}
 
 static inline uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;
@@ -54,26 +69,36 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
     const int64_t nk = k_hi - k_lo, D = f->D, W = f->row_w, P = W - 6 - (D - MCTSQ_PTG_STATE_HEAD);
     const int64_t L6 = D - MCTSQ_PTG_STATE_HEAD;
     if (nk <= 0) return 0;
-    /* one parallel region for both loops: selection, then (one thread) the slots in tree order - node ids do not depend
-       on the thread count - then action choice / environment step / node creation */
+    /* ONE parallel region, one barrier: every thread owns a contiguous run of trees, selects for it and counts its
+       expansions; after the barrier it knows its first slot (prefix over the threads' counts), so slots - and with
+       them node ids - are in tree order whatever the thread count */
     int64_t n_new = 0, bad = 0, fail = 0;
     const int64_t base = f->n;
-#pragma omp parallel if (nk >= 128)
+    int64_t counts[64];
+    int T = tree_threads();
+    if (T > 64) T = 64;
+    if (nk < 128) T = 1;
+#pragma omp parallel num_threads(T) reduction(+ : bad)
     {
-#pragma omp for schedule(static)
-        for (int64_t k = k_lo; k < k_hi; ++k) cur[k] = select_leaf(f, f->root[k], maxd, c_base, c_init);
-#pragma omp single
-        {
-            for (int64_t k = k_lo; k < k_hi; ++k) {
-                const int64_t c = cur[k];
-                if (!(f->done[c] || f->depth[c] >= maxd)) slot_node[n_new++] = k;       /* tree index for now */
-            }
-            if (n_new > stage_cap || f->n + n_new > f->cap) fail = 1;
+        const int nt = omp_get_num_threads(), tid = omp_get_thread_num();
+        const int64_t lo = k_lo + nk * tid / nt, hi = k_lo + nk * (tid + 1) / nt;
+        int64_t c = 0;
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t leaf = select_leaf(f, f->root[k], maxd, c_base, c_init);
+            cur[k] = leaf;
+            c += !(f->done[leaf] || f->depth[leaf] >= maxd);
         }
-        if (!fail) {
-#pragma omp for schedule(static) reduction(+ : bad)
-            for (int64_t s = 0; s < n_new; ++s) {
-                const int64_t k = slot_node[s], par = cur[k], id = base + s;
+        counts[tid] = c;
+#pragma omp barrier
+        int64_t s = 0, total = 0;
+        for (int t = 0; t < nt; ++t) { if (t < tid) s += counts[t]; total += counts[t]; }
+        const int over = total > stage_cap || base + total > f->cap;
+        if (tid == 0) { n_new = total; fail = over; }
+        if (!over) {
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t par = cur[k];
+                if (f->done[par] || f->depth[par] >= maxd) continue;
+                const int64_t id = base + s;
                 const int64_t mask = f->legal[par] & ~f->tried[par] & 0x1F;
                 int nb = 0, bits[N_ACT];
                 for (int a = 0; a < N_ACT; ++a)
@@ -100,37 +125,120 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
                 f->depth[id] = f->depth[par] + 1; f->done[id] = term; f->reward[id] = rew;
                 f->legal[id] = meth >= 0 && meth < 5 ? LEGAL_OF_STATE[meth] : 0x1F;
                 f->tried[id] = 0; f->nchild[id] = 0;
-                for (int c = 0; c < N_ACT; ++c) f->child[id * N_ACT + c] = -1;
+                for (int q = 0; q < N_ACT; ++q) f->child[id * N_ACT + q] = -1;
                 f->vmax[id] = 0.0; f->prior_a[id] = 0.0;
                 f->child[par * N_ACT + f->nchild[par]] = id;       /* one expansion per tree: no two slots share a parent */
                 f->nchild[par] += 1;
                 f->tried[par] |= (int64_t)1 << a;
                 if (f->depth[id] > treedepth[k]) treedepth[k] = f->depth[id];
                 cur[k] = id;
+                slot_node[s] = id;
+                ++s;
             }
         }
     }
     if (fail) return -1 - n_new;
-    for (int64_t s = 0; s < n_new; ++s) slot_node[s] = base + s;
     f->n = base + n_new;
     return bad ? -1 - bad : n_new;
 }
 
 void mctsq_lockstep_backup(mctsq_forest* f, int64_t k_lo, int64_t k_hi, const int64_t* cur, const int64_t* slot_node,
                            int64_t n_new, const float* vmax_out, const float* prior_out, int64_t n_act) {
-    for (int64_t s = 0; s < n_new; ++s) {
-        const int64_t id = slot_node[s];
-        f->vmax[id] = (double)vmax_out[s];                                  /* q.max().item() (:370) */
-        f->prior_a[id] = (double)prior_out[s * n_act + f->action[id]];      /* prior[idx, action].item() (:296) */
-    }
-#pragma omp parallel for schedule(static) if (k_hi - k_lo >= 256)
-    for (int64_t k = k_lo; k < k_hi; ++k) {
-        int64_t node = cur[k];
-        const double value = f->vmax[node];
-        while (node >= 0) {
-            f->visits[node] += 1;
-            f->total[node] += value;
-            node = f->parent[node];
+    /* Same partition of the trees over the threads as in expand: a tree's nodes are then read and written by one
+       thread in both phases and stay in that core's cache (with the backup on the calling thread alone, every line it
+       touched had to travel back to the selecting thread: 11 us per 256 trees against 3 us of arithmetic). */
+    const int64_t nk = k_hi - k_lo, first = n_new > 0 ? slot_node[0] : INT64_MAX;
+    int T = tree_threads();
+    if (T > 64) T = 64;
+    if (nk < 128) T = 1;
+#pragma omp parallel num_threads(T)
+    {
+        const int nt = omp_get_num_threads(), tid = omp_get_thread_num();
+        const int64_t lo = k_lo + nk * tid / nt, hi = k_lo + nk * (tid + 1) / nt;
+        for (int64_t k = lo; k < hi; ++k) {
+            int64_t node = cur[k];
+            if (node >= first) {                                            /* this iteration's new leaf: ids are consecutive */
+                const int64_t s = node - first;
+                f->vmax[node] = (double)vmax_out[s];                        /* q.max().item() (:370) */
+                f->prior_a[node] = (double)prior_out[s * n_act + f->action[node]];   /* prior[idx, action].item() (:296) */
+            }
+            const double value = f->vmax[node];
+            while (node >= 0) {
+                f->visits[node] += 1;
+                f->total[node] += value;
+                node = f->parent[node];
+            }
         }
     }
+}
+
+/* ---- the whole search ------------------------------------------------------------------------------------------- */
+typedef int (*forward_fn)(const void*, const float*, const void*, const float*, const float*, const float*, int64_t,
+                          float*, float*, int32_t*, float*, void*, int64_t, void*, void*);
+typedef int (*event_record_fn)(void*, void*);
+typedef int (*event_sync_fn)(void*);
+typedef int (*memcpy_fn)(void*, const void*, size_t, int, void*);
+
+static inline double now_s(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, double c_base, double c_init,
+                              uint64_t seed, uint64_t iteration0, int64_t iterations, double noise_sigma,
+                              const mctsq_leaf_eval* ev, int64_t* cur, int64_t* slots, int64_t* treedepth,
+                              double* prof) {
+    const int64_t nh = ev->halves < 1 ? 1 : (ev->halves > 4 ? 4 : ev->halves), K = f->K, cap = ev->cap;
+    const int64_t L6 = f->D - MCTSQ_PTG_STATE_HEAD, P = f->row_w - 6 - L6;
+    int64_t pend[4] = {-1, -1, -1, -1};
+    const forward_fn forward = (forward_fn)ev->forward;
+    const event_record_fn ev_record = (event_record_fn)ev->event_record;
+    const event_sync_fn ev_sync = (event_sync_fn)ev->event_sync;
+    const memcpy_fn copy = (memcpy_fn)ev->memcpy_async;
+    double t_wait = 0, t_backup = 0, t_expand = 0, t_launch = 0;
+    int64_t rc = 0;
+    for (int64_t it = 0; it <= iterations && rc == 0; ++it) {          /* the extra round only drains */
+        for (int64_t h = 0; h < nh && rc == 0; ++h) {
+            const int64_t lo = h * K / nh, hi = (h + 1) * K / nh;
+            if (hi - lo > cap) return -2;
+            if (pend[h] >= 0) {
+                double t0 = prof ? now_s() : 0.0;
+                if (pend[h] > 0) {
+                    const int e = ev_sync(ev->event[h]);
+                    if (e) { rc = -1000 - e; break; }
+                }
+                double t1 = prof ? now_s() : 0.0;
+                mctsq_lockstep_backup(f, lo, hi, cur, slots + lo, pend[h], ev->vmax[h], ev->prior[h], ev->n_act);
+                pend[h] = -1;
+                if (prof) { t_wait += t1 - t0; t_backup += now_s() - t1; }
+            }
+            if (it == iterations) continue;
+            double t0 = prof ? now_s() : 0.0;
+            const int64_t n_new = mctsq_lockstep_expand(f, env, maxd, c_base, c_init, seed, iteration0 + (uint64_t)it, lo,
+                                                        hi, noise_sigma, cur, slots + lo, ev->stage[h], cap, treedepth);
+            if (n_new < 0) { rc = n_new; break; }
+            double t1 = prof ? now_s() : 0.0;
+            if (n_new > 0) {
+                const float* in = ev->stage[h];
+                int e = 0;
+                if (ev->dev_in[h]) {
+                    in = ev->dev_in[h];
+                    e = copy(ev->dev_in[h], ev->stage[h], sizeof(float) * (size_t)(cap * f->row_w), 1, ev->stream);
+                }
+                if (!e)
+                    e = forward(ev->net, ev->params, ev->prep, in, in + cap * P, in + cap * (P + L6), n_new, ev->q[h],
+                                ev->vmax[h], ev->argmax[h], ev->prior[h], ev->ws[h], ev->ws_bytes, ev->stream, NULL);
+                if (!e) e = ev_record(ev->event[h], ev->stream);
+                if (e) { rc = -1000 - (e < 0 ? -e : e); break; }
+            }
+            pend[h] = n_new;
+            if (prof) { t_expand += t1 - t0; t_launch += now_s() - t1; }
+        }
+    }
+    if (rc != 0)                                            /* leave nothing in flight behind an error */
+        for (int64_t h = 0; h < nh; ++h)
+            if (pend[h] > 0) ev_sync(ev->event[h]);
+    if (prof) { prof[0] += t_wait; prof[1] += t_backup; prof[2] += t_expand; prof[3] += t_launch; }
+    return rc;
 }

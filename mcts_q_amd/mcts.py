@@ -63,10 +63,11 @@ class MCTSQConfiguration:
 def _device_evaluator(policy_net):
     """rows fp32 [n, 91] (host) -> (vmax [n], prior [n, A]) through ONE launch of the HIP forward."""
     dev = policy_net.device
+    fwd = policy_net.evaluate_leaves if hasattr(policy_net, "evaluate_leaves") else policy_net.forward   # DeviceQNet
 
     def evaluate(rows):
         t = torch.from_numpy(np.ascontiguousarray(rows)).to(dev, non_blocking=True)
-        out = policy_net.evaluate_leaves(*split_rows(t))
+        out = fwd(*split_rows(t))
         return out["vmax"].cpu().numpy(), out["prior"].cpu().numpy()
     return evaluate
 
@@ -117,6 +118,33 @@ class DeviceLeafEvaluator:
             self._args.append((C.byref(net.desc), ptr(net.flat), prep, base, base + 4 * cap * 25, base + 4 * cap * 85,
                                ptr(self._q[h]), self._hout[h].data_ptr(), ptr(self._arg[h]),
                                self._hout[h].data_ptr() + 4 * cap, ptr(self._ws[h]), self._ws[h].numel(), st, None))
+
+    def c_struct(self):
+        """mctsq_leaf_eval for mctsq_lockstep_search: the forward entry point and the three HIP runtime calls as
+        plain addresses (libmctsq_tree.so links no GPU runtime), buffers and events of both blocks."""
+        from .hipevents import HipEvent, _rt
+        from .treesearch import LeafEval
+        C = self._C
+        if not hasattr(self, "_hipev"):
+            self._hipev = [HipEvent() for _ in range(self.halves)]
+        hip, dll = _rt(), self._lib._load()
+        le = LeafEval()
+        addr = lambda fn: C.cast(fn, C.c_void_p).value
+        le.forward, le.event_record = addr(dll.mctsq_q_forward_prepared), addr(hip.hipEventRecord)
+        le.event_sync, le.memcpy_async = addr(hip.hipEventSynchronize), addr(hip.hipMemcpyAsync)
+        a = self._args[0]
+        le.net, le.params, le.prep = C.addressof(self.net.desc), a[1], a[2]
+        le.stream = self._stream.cuda_stream
+        le.halves, le.cap, le.ws_bytes, le.n_act = self.halves, self.cap, self._ws[0].numel(), self.n_act
+        for h in range(self.halves):
+            le.stage[h] = self._hin[h].data_ptr()
+            le.dev_in[h] = None if self.zero_copy else self._din[h].data_ptr()
+            le.q[h], le.argmax[h], le.ws[h] = self._q[h].data_ptr(), self._arg[h].data_ptr(), self._ws[h].data_ptr()
+            le.vmax[h] = self._hout[h].data_ptr()
+            le.prior[h] = self._hout[h].data_ptr() + 4 * self.cap
+            le.event[h] = self._hipev[h].ptr
+        self._le = le                                                   # keeps the desc byref alive with it
+        return le
 
     def stage_ptr(self, h):
         return self._hin[h].data_ptr()
@@ -269,7 +297,7 @@ class LockstepAgent:
 
     def __init__(self, envs, dqn: DQNModel, iterations: int, maximum_depth: int, c_base: float, c_init: float,
                  tau: float = 0.005, tree_remain_interval: int = 10, seed: int = 0, updates_per_step: int = 1,
-                 batch_env=None, n_trees: int | None = None, zero_copy: bool = False):
+                 batch_env=None, n_trees: int | None = None, zero_copy: bool = False, blocks: int = 2):
         """envs: K environments with the `_per` protocol, OR batch_env (+ n_trees): one vectorised environment
         with the batched protocol of treesearch.LockstepMCTS (reset(seeds), observe, step_batch)."""
         self.dqn, self.batch_env = dqn, batch_env
@@ -278,7 +306,7 @@ class LockstepAgent:
         if batch_env is not None:
             self.K = int(n_trees)
             if getattr(batch_env, "c_env", None):
-                halves = 2 if self.K >= 64 else 1
+                halves = max(1, min(int(blocks), 4)) if self.K >= 64 else 1
                 ev = DeviceLeafEvaluator(dqn.policy_net, -(-self.K // halves), halves, zero_copy=zero_copy)
             else:
                 ev = _device_evaluator(dqn.policy_net)

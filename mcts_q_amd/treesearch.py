@@ -76,6 +76,14 @@ class Forest(ctypes.Structure):
                                                 "child", "total", "vmax", "prior_a", "svec", "reward", "done", "rows")])
 
 
+class LeafEval(ctypes.Structure):
+    """mctsq_leaf_eval (include/mctsq_tree.h): what mctsq_lockstep_search needs to launch and await leaf batches."""
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("forward", "event_record", "event_sync", "memcpy_async", "net", "params",
+                                                "prep", "stream")] +
+                [(k, ctypes.c_int64) for k in ("halves", "cap", "ws_bytes", "n_act")] +
+                [(k, ctypes.c_void_p * 4) for k in ("stage", "dev_in", "q", "vmax", "prior", "argmax", "ws", "event")])
+
+
 class HostStagedEvaluator:
     """Adapter giving a plain evaluate(rows) -> (vmax, prior) function the staged interface the C driver feeds
     (stage_ptr / launch / wait / vmax_ptr / prior_ptr, `halves` independent staging areas of `cap` slots each).
@@ -139,6 +147,9 @@ def _tree_lib():
         L.mctsq_lockstep_expand.restype = I64
         L.mctsq_lockstep_backup.argtypes = [ctypes.POINTER(Forest), I64, I64, P, P, I64, P, P, I64]
         L.mctsq_lockstep_backup.restype = None
+        L.mctsq_lockstep_search.argtypes = [ctypes.POINTER(Forest), P, I64, F64, F64, U64, U64, I64, F64,
+                                            ctypes.POINTER(LeafEval), P, P, P, P]
+        L.mctsq_lockstep_search.restype = I64
         L.mctsq_lockstep_uniform.argtypes = [U64, U64, U64, U64]
         L.mctsq_lockstep_uniform.restype = F64
         _TREE_LIB = L
@@ -197,7 +208,7 @@ class LockstepMCTS:
         if self.fast:
             if int(batch_env.row_width) != ROW:
                 raise ValueError(f"the leaf batch layout needs {ROW}-scalar observations, the environment has {batch_env.row_width}")
-            if not hasattr(evaluate, "launch"):
+            if not (hasattr(evaluate, "launch") or hasattr(evaluate, "c_struct")):
                 self.evaluate = HostStagedEvaluator(evaluate, -(-self.K // 2) if self.K >= 64 else self.K, ROW, N_ACT,
                                                     2 if self.K >= 64 else 1)
 
@@ -530,13 +541,31 @@ class LockstepMCTS:
         if max(hi - lo for lo, hi in bounds) > ev.cap:
             raise ValueError("leaf staging area smaller than a block of trees")
         cur = np.empty(K, dtype=np.int64)
-        slots = [np.empty(hi - lo, dtype=np.int64) for lo, hi in bounds]
+        slot_all = np.empty(K, dtype=np.int64)
+        slots = [slot_all[lo:hi] for lo, hi in bounds]
         pend = [None] * nh
         env, sigma = self.batch_env.c_env, float(self.batch_env.noise)
         cb, ci, A = float(self.c_base), float(self.c_init), N_ACT
         curp, tdp = cur.ctypes.data, self.treedepth.ctypes.data
         ev.begin()
 
+        if hasattr(ev, "c_struct"):          # device evaluator: the whole loop in ONE C call (no Python per iteration)
+            le = ev.c_struct()
+            if nh != le.halves or max(hi - lo for lo, hi in bounds) > le.cap:
+                raise ValueError("leaf evaluator blocks do not match the driver's")
+            parr = (ctypes.c_double * 4)(0, 0, 0, 0) if self.prof is not None else None
+            rc = L.mctsq_lockstep_search(fp, env, maxd, cb, ci, self.seed, self.iter_count, self.iterations, sigma,
+                                         ctypes.byref(le), curp, slot_all.ctypes.data, tdp, parr)
+            if rc < 0:
+                raise (IndexError(f"environment step failed for {-1 - rc} states (clock outside the price tables, or "
+                                  "staging / node capacity exceeded)") if rc > -1000 else
+                       RuntimeError(f"leaf batch launch failed with code {-1000 - rc}"))
+            if parr is not None:
+                for q, k in enumerate(("wait", "backup", "expand", "launch")):
+                    self.prof[k] += parr[q]
+            self.iter_count += self.iterations
+            self.n = int(f.n)
+            return
         prof = self.prof                     # optional wall-clock split {wait, backup, expand, launch} (tools/tree_bench.py)
         clock = time.perf_counter
 

@@ -259,3 +259,72 @@ def test_c_lockstep_driver_equals_numpy_driver_on_the_ptg_environment(K, iters, 
         for u, v in zip(x, y):
             assert np.array_equal(u, v)
     assert (runs[0][0][2][:1] >= 1).all() and int(runs[0][2][1]) > K
+
+
+class _CallbackEvaluator:
+    """HostStagedEvaluator whose launch / wait are handed to mctsq_lockstep_search as C function pointers (ctypes
+    callbacks standing in for mctsq_q_forward_prepared / hipEventRecord / hipEventSynchronize)."""
+
+    def __init__(self, cap, halves):
+        import ctypes
+        from mcts_q_amd.treesearch import HostStagedEvaluator, LeafEval
+        self.h = HostStagedEvaluator(_hash_eval, cap, halves=halves)
+        self.cap, self.halves, self.calls = cap, halves, []
+        FWD = ctypes.CFUNCTYPE(ctypes.c_int, *([ctypes.c_void_p] * 6 + [ctypes.c_int64] + [ctypes.c_void_p] * 5 +
+                                               [ctypes.c_int64] + [ctypes.c_void_p] * 2))
+        EV2 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+        EV1 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+
+        def forward(net, params, prep, price, proc, gas, n, q, vmax, argmax, prior, ws, ws_bytes, stream, mid):
+            h = [self.h.stage_ptr(x) for x in range(halves)].index(price)
+            assert proc == price + 4 * cap * 25 and gas == price + 4 * cap * 85 and vmax == self.h.vmax_ptr(h)
+            self.calls.append((h, n))
+            self.h.launch(h, n)
+            return 0
+        self._keep = (FWD(forward), EV2(lambda e, s: 0), EV1(lambda e: 0))
+        le = LeafEval()
+        le.forward, le.event_record, le.event_sync = (ctypes.cast(f, ctypes.c_void_p).value for f in self._keep)
+        le.halves, le.cap, le.n_act = halves, cap, 5
+        for h in range(halves):
+            le.stage[h], le.vmax[h], le.prior[h] = self.h.stage_ptr(h), self.h.vmax_ptr(h), self.h.prior_ptr(h)
+        self.le = le
+
+    def __call__(self, rows):
+        return _hash_eval(rows)
+
+    def begin(self):
+        pass
+
+    def c_struct(self):
+        return self.le
+
+
+@pytest.mark.parametrize("K,iters,blocks", [(20, 15, 1), (200, 10, 2), (200, 7, 3), (130, 7, 4)])
+def test_whole_search_in_one_c_call_equals_the_per_iteration_driver(K, iters, blocks):
+    """mctsq_lockstep_search (the loop over iterations and blocks inside C, leaf batches through function pointers)
+    builds the same trees as the per-iteration calls from Python."""
+    from mcts_q_amd.ptgenv import PtGBatchEnv
+    from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
+    kw = synthetic_ptg_kwargs(6, scale=0.2)
+    runs = []
+    for one_call in (True, False):
+        env = PtGBatchEnv(kw, seed=1)
+        halves = blocks
+        ev = _CallbackEvaluator(-(-K // halves), halves) if one_call else _hash_eval
+        drv = LockstepMCTS(K, ev, iters, 6, 19652, 1.25, batch_env=env, seed=5)
+        drv.prof = dict(wait=0.0, backup=0.0, expand=0.0, launch=0.0)
+        states = env.reset(np.arange(K))
+        rec = []
+        for step in range(3):
+            a = drv.predict(states, train=True, reuse=np.ones(K, dtype=bool))
+            n = drv.n
+            rec.append([a.copy(), np.array(n), drv.visits[:n].copy(), drv.total[:n].copy(), drv.parent[:n].copy(),
+                        drv.prior_a[:n].copy(), drv.treedepth.copy(), np.array(drv.iter_count)])
+            states = env.step_batch(states, a, noise=np.zeros(K))[0]
+            drv.advance(a, keep=np.ones(K, dtype=bool))
+        runs.append(rec)
+        if one_call:
+            assert len(ev.calls) == 3 * iters * halves and drv.prof["expand"] > 0
+    for x, y in zip(*runs):
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v)

@@ -26,7 +26,8 @@ if mode in ("ptg", "ptg0"):
     from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
     benv = PtGBatchEnv(synthetic_ptg_kwargs(0, scale=1.0, train_days=46, env_values=dict(eps_len_d=40)), seed=1)
     agent = LockstepAgent(None, dqn, iterations=iters, maximum_depth=42, c_base=19652, c_init=1.25,
-                          batch_env=benv, n_trees=K, zero_copy=(mode == "ptg0"))
+                          batch_env=benv, n_trees=K, zero_copy=(mode == "ptg0"),
+                          blocks=int(os.environ.get("MCTSQ_BLOCKS", "2")))
 elif mode == "batch":
     agent = LockstepAgent(None, dqn, iterations=iters, maximum_depth=42, c_base=19652, c_init=1.25,
                           batch_env=FakeBatchEnv(), n_trees=K)
