@@ -16,6 +16,7 @@ constexpr int MAX_F = 8;       // widest per-step feature vector (process 6 + 2 
 constexpr float LN_EPS = 1e-5f;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void set_error(const char* fmt, ...);

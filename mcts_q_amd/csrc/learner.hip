@@ -330,21 +330,60 @@ struct GruBwdLds {
     float red[3][4][TILE];
 };
 
+// RPL = sample rows per lane: 4 = one workgroup per 16-sample tile; 2 = one workgroup per HALF tile (8 samples, the
+// rows r in {2h, 2h+1} of every lane's four): the matrix products keep their 16-row shape (the unused rows of the
+// delta tile are zero and their outputs are never read), but every per-(row, unit) vector instruction, LDS write
+// and global access is issued for two rows instead of four.  At the training batch a 16-sample tiling leaves three
+// quarters of the CUs idle while the step's serial chain is bound by exactly those instructions, so twice the
+// workgroups at half the vector work each shorten the chain (launch_gru_bwd picks the mode).
+template <int RPL>
+struct RowVec {
+    float v[RPL];
+    __device__ float& operator[](int r) { return v[r]; }
+    __device__ const float& operator[](int r) const { return v[r]; }
+};
+template <int RPL>
+__device__ __forceinline__ RowVec<RPL> load_rows(const float* p) {
+    RowVec<RPL> o;
+    if constexpr (RPL == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        o.v[0] = t[0]; o.v[1] = t[1]; o.v[2] = t[2]; o.v[3] = t[3];
+    } else {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+        o.v[0] = t[0]; o.v[1] = t[1];
+    }
+    return o;
+}
+template <int RPL>
+__device__ __forceinline__ void store_rows(float* p, const RowVec<RPL>& x) {
+    if constexpr (RPL == 4) *reinterpret_cast<f32x4*>(p) = (f32x4){x.v[0], x.v[1], x.v[2], x.v[3]};
+    else *reinterpret_cast<f32x2*>(p) = (f32x2){x.v[0], x.v[1]};
+}
+
+template <int RPL>
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     __shared__ __attribute__((aligned(16))) GruBwdLds L;
+    constexpr int NH = 4 / RPL;                                // workgroups per 16-sample tile
     const int slot = blockIdx.x % args.nslots;
-    const int64_t row0 = (int64_t)(blockIdx.x / args.nslots) * TILE;
+    const int hb = blockIdx.x / args.nslots;
+    const int64_t tile = hb / NH;
+    const int rb = (hb % NH) * RPL;                            // first of this workgroup's rows within a lane's four
+    const int64_t row0 = tile * TILE;
     const GruSlot& s = args.slot[slot];
     const int lane = threadIdx.x & 63, wq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), jl = lane & 15, q = lane >> 4;
     const int j = 16 * wq + jl;
     const int S = s.S;
     const int64_t Bp = args.Bp;
-    // lane-major records (kernels.hpp: GruSlot): block (t, tile, wave) is 256 floats, this lane's four rows one float4
-    const int64_t ntile = Bp / TILE, tile = row0 / TILE;
-    const int lo4 = lane * 4;
+    // lane-major records (kernels.hpp: GruSlot): block (t, tile, wave) is 256 floats, a lane's four rows one float4
+    const int64_t ntile = Bp / TILE;
+    const int lo4 = lane * 4 + rb;
     auto rec = [&](const float* base, int t) {
-        return *reinterpret_cast<const f32x4*>(base + (((int64_t)t * ntile + tile) * 4 + wq) * 256 + lo4);
+        return load_rows<RPL>(base + (((int64_t)t * ntile + tile) * 4 + wq) * 256 + lo4);
     };
+    if constexpr (RPL != 4) {                                  // rows of the delta tile this workgroup never writes
+        unsigned short* z = &L.gp[0][0][0];
+        for (int i = threadIdx.x; i < 2 * 3 * TILE * GPL / 2; i += 256) reinterpret_cast<unsigned*>(z)[i] = 0u;
+    }
 
     // W_hh as B operand of the delta . W_hh product (k = gate row, col = unit j): prepared split-bf16 fragments,
     // 6 K chunks x 3 planes resident in 72 VGPRs.  The product runs on the bf16 matrix instruction over the exact
@@ -360,12 +399,12 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     const float lnw = s.lnw[j], awj = s.aw[j];
 
     // ---- LayerNorm backward -> dpool -------------------------------------------------------
-    float dpool[4], pooled[4], mrun[4], linv[4];
+    float dpool[RPL], pooled[RPL], mrun[RPL], linv[RPL];
     {
-        float dxh[4], xh[4], rs[4];
+        float dxh[RPL], xh[RPL], rs[RPL];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 4 * q + r;
+        for (int r = 0; r < RPL; ++r) {
+            const int64_t row = row0 + 4 * q + rb + r;
             const float4 st = *reinterpret_cast<const float4*>(s.sv_stat + row * 4);
             mrun[r] = st.x; linv[r] = 1.0f / st.y; rs[r] = st.w;
             pooled[r] = s.sv_pool[row * E + j];
@@ -378,7 +417,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             const int i = 4 * q + r;
             const float s1 = ((L.red[0][0][i] + L.red[0][1][i]) + (L.red[0][2][i] + L.red[0][3][i])) * (1.0f / E);
             const float s2 = ((L.red[1][0][i] + L.red[1][1][i]) + (L.red[1][2][i] + L.red[1][3][i])) * (1.0f / E);
@@ -387,28 +426,29 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     }
     // ---- attention pooling backward: D = dpool . pooled, e_t = dpool . h_t ---------------
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RPL; ++r) {
         const float v = row16_sum(dpool[r] * pooled[r]);
         if (jl == 0) L.red[2][wq][4 * q + r] = v;
     }
-    for (int t0 = 0; t0 < S; t0 += 8) {                       // 8 x 16 bytes in flight per lane, then the sums
-        f32x4 hv[8];
+    for (int t0 = 0; t0 < S; t0 += 8) {                       // 8 records in flight per lane, then the sums
+        RowVec<RPL> hv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) hv[u] = t0 + u < S ? rec(s.sv_h, t0 + u + 1) : (f32x4){0, 0, 0, 0};
+        for (int u = 0; u < 8; ++u)
+            if (t0 + u < S) hv[u] = rec(s.sv_h, t0 + u + 1);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (t0 + u >= S) break;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RPL; ++r) {
                 const float v = row16_sum(dpool[r] * hv[u][r]);
                 if (jl == 0) (&L.pe[t0 + u][4 * q + r].x)[wq] = v;
             }
         }
     }
     __syncthreads();
-    float Dd[4];
+    float Dd[RPL];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < RPL; ++r) {
         const int i = 4 * q + r;
         Dd[r] = (L.red[2][0][i] + L.red[2][1][i]) + (L.red[2][2][i] + L.red[2][3][i]);
     }
@@ -416,41 +456,42 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     // ---- BPTT ----------------------------------------------------------------------------
     // The saved activations of the steps ahead are fetched while the current step's MFMA chain runs, so the
     // recurrence never waits on HBM/L2 latency.
-    struct StepIn { f32x4 rg, zg, ng, hn, hprev; float sc[4]; };
+    struct StepIn { RowVec<RPL> rg, zg, ng, hn, hprev, sc; };
     StepIn sb0, sb1, sb2;                  // three steps of saved activations in flight (HBM latency > one step)
-    const float* scp = s.sv_score + row0 + 4 * q;
+    const float* scp = s.sv_score + row0 + 4 * q + rb;
     auto fetch = [&](StepIn& d, int t) {
         d.rg = rec(s.sv_r, t); d.zg = rec(s.sv_z, t); d.ng = rec(s.sv_n, t); d.hn = rec(s.sv_hn, t);
         d.hprev = rec(s.sv_h, t);                              // block t = h_{t-1}
-        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(scp + (int64_t)t * Bp);
-        d.sc[0] = sc4[0]; d.sc[1] = sc4[1]; d.sc[2] = sc4[2]; d.sc[3] = sc4[3];
+        d.sc = load_rows<RPL>(scp + (int64_t)t * Bp);
     };
     fetch(sb0, S - 1);
     if (S >= 2) fetch(sb1, S - 2);
     if (S >= 3) fetch(sb2, S - 3);
     // gradient of the score Linear(64,1): d_aw[j] = sum_{t,row} dsc * h_t[row][j], d_ab = sum dsc.  h_t is
-    // the h_{t-1} operand of the step handled just before (the loop runs backwards); the tile's sums
-    // go out as one partial, reduced over tiles in order by wgrad_reduce_kernel.
+    // the h_{t-1} operand of the step handled just before (the loop runs backwards); the workgroup's sums
+    // go out as one partial, reduced over workgroups in order by wgrad_reduce_kernel.
     float daw = 0.0f, dab = 0.0f;
-    f32x4 hnext = rec(s.sv_h, S);
-    float dhc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    RowVec<RPL> hnext = rec(s.sv_h, S);
+    float dhc[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) dhc[r] = 0.0f;
     auto bptt_step = [&](int t, StepIn& cur) {
         const int buf = t & 1;
-        float zs[4], dhs[4], dsc[4], at[4];
+        float zs[RPL], dhs[RPL], dsc[RPL], at[RPL];
         // everything read from LDS first, so that no read has to queue behind this step's plane writes
         {
-            float4 pe[4];
+            float4 pe[RPL];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pe[r] = L.pe[t][4 * q + r];
+            for (int r = 0; r < RPL; ++r) pe[r] = L.pe[t][4 * q + r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RPL; ++r) {
                 at[r] = fast_exp2(cur.sc[r] - mrun[r]) * linv[r];
                 dsc[r] = at[r] * (((pe[r].x + pe[r].y) + (pe[r].z + pe[r].w)) - Dd[r]);
             }
         }
-        f32x4 g0, g1, g2, g3;
+        RowVec<RPL> g0, g1, g2, g3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             const int i = 4 * q + r;
             const float rg = cur.rg[r], zg = cur.zg[r], ng = cur.ng[r], hn = cur.hn[r], hprev = cur.hprev[r];
             daw = fmaf(dsc[r], hnext[r], daw); dab += dsc[r];
@@ -476,29 +517,41 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         hnext = cur.hprev;
         {                                                      // d(pre-activation) record for the weight gradients
             float* gb = s.bw_g + ((((int64_t)t * ntile + tile) * 4) * 4 + wq) * 256 + lo4;
-            *reinterpret_cast<f32x4*>(gb) = g0; *reinterpret_cast<f32x4*>(gb + 1024) = g1;
-            *reinterpret_cast<f32x4*>(gb + 2048) = g2; *reinterpret_cast<f32x4*>(gb + 3072) = g3;
+            store_rows<RPL>(gb, g0); store_rows<RPL>(gb + 1024, g1);
+            store_rows<RPL>(gb + 2048, g2); store_rows<RPL>(gb + 3072, g3);
         }
         if (t >= 3) fetch(cur, t - 3);                         // this buffer's next occupant starts its trip
         if (t == 0) return;                                    // dh_{-1} is not needed
         __syncthreads();
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
         {
+            // Three accumulators, one K chunk each per half, their MFMAs issued round-robin so that consecutive
+            // instructions never depend on each other; the second half's nine fragments are requested from LDS
+            // before the first half's products start.
             const int o = (lane & 15) * GPL + 8 * q;
-#define GB_MM6(ACC, C)                                                                                         \
-            {                                                                                                  \
-                const u32x4 xh = *reinterpret_cast<const u32x4*>(&L.gp[buf][0][o + 32 * (C)]);                 \
-                const u32x4 xm = *reinterpret_cast<const u32x4*>(&L.gp[buf][1][o + 32 * (C)]);                 \
-                const u32x4 xl = *reinterpret_cast<const u32x4*>(&L.gp[buf][2][o + 32 * (C)]);                 \
-                ACC = mfma_bf(xl, wt[C][0], ACC); ACC = mfma_bf(xh, wt[C][2], ACC); ACC = mfma_bf(xm, wt[C][1], ACC); \
-                ACC = mfma_bf(xm, wt[C][0], ACC); ACC = mfma_bf(xh, wt[C][1], ACC); ACC = mfma_bf(xh, wt[C][0], ACC); \
-            }
-            GB_MM6(acc0, 0) GB_MM6(acc1, 2) GB_MM6(acc2, 4)
-            GB_MM6(acc0, 1) GB_MM6(acc1, 3) GB_MM6(acc2, 5)
-#undef GB_MM6
+            u32x4 xa[3][3], xb[3][3];                         // [chunk of the half][plane]
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xa[c][pl] = *reinterpret_cast<const u32x4*>(&L.gp[buf][pl][o + 32 * (2 * c)]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xb[c][pl] = *reinterpret_cast<const u32x4*>(&L.gp[buf][pl][o + 32 * (2 * c + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+            // cross terms smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); x plane / w plane
+#define GB_TERM(X, CH, XP, WP)                                                                     \
+            acc0 = mfma_bf(X[0][XP], wt[0 + CH][WP], acc0);                                        \
+            acc1 = mfma_bf(X[1][XP], wt[2 + CH][WP], acc1);                                        \
+            acc2 = mfma_bf(X[2][XP], wt[4 + CH][WP], acc2);
+            GB_TERM(xa, 0, 2, 0) GB_TERM(xa, 0, 0, 2) GB_TERM(xa, 0, 1, 1)
+            GB_TERM(xa, 0, 1, 0) GB_TERM(xa, 0, 0, 1) GB_TERM(xa, 0, 0, 0)
+            GB_TERM(xb, 1, 2, 0) GB_TERM(xb, 1, 0, 2) GB_TERM(xb, 1, 1, 1)
+            GB_TERM(xb, 1, 1, 0) GB_TERM(xb, 1, 0, 1) GB_TERM(xb, 1, 0, 0)
+#undef GB_TERM
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             dhc[r] = dhs[r] * zs[r] + ((acc0[r] + acc1[r]) + acc2[r]);
         }
     };
@@ -509,7 +562,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     }
     daw += __shfl_xor(daw, 16, 64); daw += __shfl_xor(daw, 32, 64);
     dab += __shfl_xor(dab, 16, 64); dab += __shfl_xor(dab, 32, 64);
-    float* pa = s.bw_aw + (row0 / TILE) * 65;
+    float* pa = s.bw_aw + (int64_t)hb * 65;                    // one partial per workgroup: [Bp/16 * NH][65]
     if (q == 0) pa[j] = daw;
     if (wq == 0 && lane == 0) pa[64] = dab;
 }
@@ -561,7 +614,8 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
     for (int i = 0; i < a.nslots; ++i) MCTSQ_CHECK(a.slot[i].S <= MAX_SEQ, "window too long");
     for (int i = 0; i < a.nslots; ++i)
         MCTSQ_CHECK(a.slot[i].wprep_t && ((uintptr_t)a.slot[i].wprep_t & 15) == 0, "GRU backward needs the transposed prepared weights");
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)(a.Bp / TILE * a.nslots)), dim3(256), 0, st, a);
+    if (a.half) hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3((unsigned)(a.Bp / TILE * 2 * a.nslots)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gru_bwd_kernel<4>, dim3((unsigned)(a.Bp / TILE * a.nslots)), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -52,6 +52,7 @@ struct GruBwdArgs {
     int nslots;
     int64_t Bp;
     const float* dfeat;         // [Bp][192]
+    int half;                   // 1: one workgroup per 8 samples (gru_bwd_kernel<2>), bw_aw partials [Bp/8][65]
 };
 // W_hh [192][64] as the B operand of the BPTT product delta [16 x 192] . W_hh: u32x4 [wave 4][K chunk 6][plane 3][lane 64],
 // lane (jl, q) of wave w holds W_hh[32c + 8q .. +7][16w + jl]; GRU_PREP_BYTES per slot

@@ -94,7 +94,7 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
             g.wp_ih = c.take((int64_t)g.gw_nsplit * (G3 * e.F + G3));
             g.wp_rz = c.take((int64_t)g.gw_nsplit * (128 * E + 128));
             g.wp_n = c.take((int64_t)g.gw_nsplit * (E * E + E));
-            g.wp_aw = c.take(Bp / TILE * 65);
+            g.wp_aw = c.take(Bp / TILE * 2 * 65);       // per workgroup of the GRU backward (8- or 16-sample tiles)
             g.wt = c.take(GRU_PREP_BYTES / (int64_t)sizeof(float));
             pf += 2 * job_partial_floats(E, 0, Bp);
         } else if (e.kind == MCTSQ_ENC_CONV) {
@@ -196,7 +196,7 @@ namespace {
 // also legal under stream capture).  One helper stream and event set per (device, caller stream), created on first
 // use and kept for the life of the process, so calls on different streams never share events; calls on the SAME
 // stream are ordered by the caller (one host thread enqueues on a stream at a time).
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, head = nullptr, join2 = nullptr; };
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, head = nullptr, join2 = nullptr, upd = nullptr; };
 std::mutex g_side_mu;
 std::map<std::pair<int, void*>, SideStream> g_side;
 int side_stream(hipStream_t caller, SideStream* out) {
@@ -210,6 +210,7 @@ int side_stream(hipStream_t caller, SideStream* out) {
         MCTSQ_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.head, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.join2, hipEventDisableTiming));
+        MCTSQ_HIP(hipEventCreateWithFlags(&s.upd, hipEventDisableTiming));
     }
     *out = s;
     return 0;
@@ -340,10 +341,12 @@ static int dqn_grad_entry(const mctsq_net_desc* net, const DqnPrep* pp, const fl
     const int rc = dqn_grad_enqueue(L, P, &side, pp, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice,
                                     d_nprocess, d_ngas, d_act, d_rew, d_done, d_isw, gamma, loss_scale, B, d_grad,
                                     d_loss, d_abs_td, d_qsa, d_target, d_sumsq_parts, upd, (float*)d_ws, st);
-    if (rc != 0) {                     // whatever was enqueued on the helper stream is joined back before returning
+    if (rc < 0) {                      // whatever was enqueued on the helper stream is joined back before returning
         (void)hipEventRecord(side.join2, side.st);
         (void)hipStreamWaitEvent(st, side.join2, 0);
     }
+    // success: the helper lane was joined before the reduction; only the priority write-back (upd) may still be running
+    // there - its caller (mctsq_per_dqn_step) joins it at the end of the step, behind the optimizer
     return rc;
 }
 
@@ -491,9 +494,6 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     }
     MCTSQ_HIP(hipEventRecord(side->head, st));
     MCTSQ_HIP(hipStreamWaitEvent(side->st, side->head, 0));
-    if (upd && launch_per_update(upd->tree, upd->prio, upd->stamp, upd->cap, upd->head, upd->size, upd->idx, d_abs_td, B,
-                                 upd->alpha, upd->mass_cap, side->st))
-        return -1;
 
     // 5./6. encoder backward (deltas) and weight gradients (every tensor is one or a few K-contractions), on two
     // lanes: `jbA` holds the products that need only the head's deltas, `jbB` those behind the encoder backward
@@ -501,6 +501,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     GruWgradArgs gwMain, gwSide;
     memset(&gwMain, 0, sizeof(gwMain));
     memset(&gwSide, 0, sizeof(gwSide));
+    int gru_half[2] = {0, 0};                                 // tile mode of the GRU backward per lane (caller's, helper)
     // the longest GRU window stays on the caller's stream, the others go to the helper stream
     int long_slot = -1;
     for (int s = 0; s < 3; ++s)
@@ -525,6 +526,14 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             gb.slot[gb.nslots] = ga.slot[i++];
             gb.slot[gb.nslots].wprep_t = gru_bwd_prep[s];
             ++gb.nslots;
+        }
+        // 8-sample tiles (half the per-step vector work per workgroup, see gru_bwd_kernel) while the launch still fits the
+        // chip in one wave of workgroups: for both lanes, else for the long window on the caller's stream only
+        {
+            const int64_t nt = Bp / TILE;
+            if (2 * nt * (gbMain.nslots + gbSide.nslots) <= 256) gbMain.half = gbSide.half = 1;
+            else if (nt * (2 * gbMain.nslots + gbSide.nslots) <= 256) gbMain.half = 1;
+            gru_half[0] = gbMain.half; gru_half[1] = gbSide.half;
         }
         if (launch_gru_bwd(gbSide, side->st)) return -1;
         if (launch_gru_bwd(gbMain, st)) return -1;
@@ -588,7 +597,8 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             if (jbB.add_external(g.wp_n - P.partials, E, E, g.gw_nsplit, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E))
                 return -1;
             // attention score Linear(64,1): d(score) x h_t, per-tile partials written by gru_bwd_kernel
-            if (jbB.add_external(g.wp_aw - P.partials, 1, E, (int)(Bp / TILE), e.gru.aw, E, 1, e.gru.ab)) return -1;
+            if (jbB.add_external(g.wp_aw - P.partials, 1, E, (int)(Bp / TILE) * (gru_half[s == long_slot ? 0 : 1] ? 2 : 1),
+                                 e.gru.aw, E, 1, e.gru.ab)) return -1;
             // LayerNorm weight / bias: column sums over the batch
             // (dfeat * xhat is written by this slot's backward: a short window's runs on the helper stream, ahead of jbA)
             if (s == long_slot) { if (addB(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1; }
@@ -646,6 +656,15 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st)) return -1;
     if (launch_gru_wgrad(gwSide, side->st)) return -1;
     MCTSQ_HIP(hipEventRecord(side->join2, side->st));
+    // the priority write-back (needs only |td| of the head backward) goes LAST on the helper lane: it then runs next
+    // to the reduction on the caller's stream instead of ahead of the short windows' backward, where it sat on the
+    // path to join2 (the two lanes are balanced to a few microseconds); the caller's stream picks it up below
+    if (upd) {
+        if (launch_per_update(upd->tree, upd->prio, upd->stamp, upd->cap, upd->head, upd->size, upd->idx, d_abs_td, B,
+                              upd->alpha, upd->mass_cap, side->st))
+            return -1;
+        MCTSQ_HIP(hipEventRecord(side->upd, side->st));
+    }
     // caller's stream: the long window's weight gradients and everything else behind the encoder backward
     if (launch_gru_wgrad(gwMain, st)) return -1;
     for (int i = 0; i < jbB.nlists; ++i)
@@ -768,6 +787,12 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
     if (rc) return rc;
     rc = mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd,
                            stream);
+    // the priority write-back ran on the helper lane next to reduction / optimizer: join it here, so that everything of
+    // the step is ordered before whatever the caller enqueues next (by now the event has long fired: waiting for it
+    // ahead of the optimizer cost a dependent cross-queue hand-off on the critical path)
+    SideStream side;
+    if (side_stream((hipStream_t)stream, &side)) return -1;
+    MCTSQ_HIP(hipStreamWaitEvent((hipStream_t)stream, side.upd, 0));
     if (rc) return rc;
     return 0;
 }

@@ -52,6 +52,9 @@ def test_host_tree_helper_exports_its_header():
     assert env == ["mctsq_ptg_create", "mctsq_ptg_destroy", "mctsq_ptg_info", "mctsq_ptg_observe", "mctsq_ptg_reset",
                    "mctsq_ptg_state_dim", "mctsq_ptg_step", "mctsq_ptg_step_one"]
     assert all(hasattr(dll, n) for n in env)
+    drv = sorted(set(re.findall(r"\b(mctsq_lockstep_[a-z0-9_]+)\s*\(", text)))
+    assert drv == ["mctsq_lockstep_backup", "mctsq_lockstep_expand", "mctsq_lockstep_search", "mctsq_lockstep_uniform"]
+    assert all(hasattr(dll, n) for n in drv)
 
 
 def test_encoder_layout_query_needs_no_gpu():
