@@ -23,7 +23,7 @@ static void fill_gru_slot(GruSlot& g, const EncOff& e, const float* params, cons
     if (sv) {
         g.sv_h = sv->h; g.sv_r = sv->r; g.sv_z = sv->z; g.sv_n = sv->n; g.sv_hn = sv->hn;
         g.sv_score = sv->score; g.sv_stat = sv->stat; g.sv_pool = sv->pool; g.sv_x = sv->x;
-        g.bw_g = sv->g; g.bw_dsc = sv->dsc; g.bw_p = sv->p; g.bw_aw = sv->aw;
+        g.bw_g = sv->g; g.bw_dsc = sv->dsc; g.bw_p = sv->p; g.bw_aw = sv->aw; g.bw_ln = sv->ln;
     }
 }
 
@@ -162,6 +162,41 @@ void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* 
 
 // TripleEncoderDQN.forward (dqn_per.py:232-236) + leaf epilogue.  `sv` != NULL keeps the
 // activations the backward pass needs (training) and always takes the per-encoder kernels.
+// head arguments of one forward (shared by forward_impl and forward_pair_impl)
+static void fill_head_args(HeadArgs& ha, const NetLayout& L, const float* params, const void* prep, int64_t B, int64_t Bp,
+                           float* feats, const HeadOut& out, const SlotSave* sv, float* const* sv_act) {
+    memset(&ha, 0, sizeof(ha));
+    ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
+    for (int i = 0; i < L.n_fc; ++i) {
+        ha.w[i] = params + L.fc_w[i]; ha.b[i] = params + L.fc_b[i];
+        ha.in[i] = L.fc_in[i]; ha.out[i] = L.fc_out[i];
+    }
+    ha.q = out.q; ha.vmax = out.vmax; ha.argmax = out.argmax; ha.prior = out.prior;
+    if (sv != nullptr)
+        for (int i = 0; i + 1 < L.n_fc; ++i) ha.sv_act[i] = sv_act[i];
+    if (head_bf16_layout(L) && prep)
+        ha.wprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L);
+}
+
+// Policy forward on s (records kept) and target forward on s' as ONE launch.  Returns 1 (nothing enqueued) when the
+// network is not the fused gru/gru/gru shape or a prepared-weights buffer is missing: the caller then issues the two
+// forwards separately.
+int forward_pair_impl(const NetLayout& L, const float* params, const void* prep, const float* const x[3], float* ws_p,
+                      const HeadOut& out_p, const SlotSave* sv, float* const* sv_act, const float* tparams,
+                      const void* tprep, const float* const xt[3], float* ws_t, const HeadOut& out_t, int64_t B,
+                      int64_t Bp, hipStream_t st) {
+    if (!prep || !tprep || !sv) return 1;
+    GruFwdArgs g0, g1;
+    fill_gru_args(g0, L, params, prep, x, B, Bp, ws_p, sv);
+    fill_gru_args(g1, L, tparams, tprep, xt, B, Bp, ws_t, nullptr);
+    HeadArgs h0, h1;
+    fill_head_args(h0, L, params, prep, B, Bp, ws_p, out_p, sv, sv_act);
+    fill_head_args(h1, L, tparams, tprep, B, Bp, ws_t, out_t, nullptr, nullptr);
+    if (!fused_gru_head_applicable(g0, h0) || !fused_gru_head_applicable(g1, h1)) return 1;
+    g1.feats = nullptr;
+    return launch_gru3_head_fwd_pair(g0, h0, g1, h1, st) ? -1 : 0;
+}
+
 int forward_impl(const NetLayout& L, const float* params, const void* prep, const float* const x[3], int64_t B,
                  int64_t Bp, float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
                  void* ev_encoders_done) {
@@ -180,17 +215,8 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     const bool has_tf = L.enc[0].kind == MCTSQ_ENC_TRANSFORMER || L.enc[1].kind == MCTSQ_ENC_TRANSFORMER;
     (void)has_tf;
     HeadArgs ha;
-    memset(&ha, 0, sizeof(ha));
-    ha.feats = feats; ha.n_fc = L.n_fc; ha.act = L.act; ha.A = L.A; ha.B = B; ha.Bp = Bp;
-    for (int i = 0; i < L.n_fc; ++i) {
-        ha.w[i] = params + L.fc_w[i]; ha.b[i] = params + L.fc_b[i];
-        ha.in[i] = L.fc_in[i]; ha.out[i] = L.fc_out[i];
-    }
-    ha.q = out.q; ha.vmax = out.vmax; ha.argmax = out.argmax; ha.prior = out.prior;
+    fill_head_args(ha, L, params, prep, B, Bp, feats, out, sv, sv_act);
     const bool save = sv != nullptr;
-    if (save)
-        for (int i = 0; i + 1 < L.n_fc; ++i) ha.sv_act[i] = sv_act[i];
-    if (head_bf16_layout(L)) ha.wprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L) + tf_prepared_bytes(L);
 
     if (fused_gru_head_applicable(ga, ha)) {                 // shipped default: one launch
         // (measured at the training batch, 64 tiles: the per-window kernels + head kernel take 38 + 9 us against 53

@@ -10,7 +10,7 @@ struct SlotSave {
     // shared by the attention-pooled encoders (GRU, conv)
     float *score, *stat, *pool, *x, *dsc, *p;
     // GRU-attention (kernels.hpp: GruSlot)
-    float *h, *r, *z, *n, *hn, *g, *aw;
+    float *h, *r, *z, *n, *hn, *g, *aw, *ln;
     // Conv-attention (kernels.hpp: ConvSlot)
     float *c_h1, *c_h2, *c_d2, *c_d1;
     // gas/EUA MLP (kernels.hpp: MlpArgs)
@@ -42,6 +42,11 @@ int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_
 void fill_tf_args(TfArgs& t, const EncOff& e, const float* params, const float* x, int slot, int64_t B,
                   int64_t Bp, float* feats, float* hbuf, const SlotSave* sv);
 // prep: prepared weights of `params` (prepare_impl), or NULL to prepare them into the workspace first
+// policy forward (records kept) + target forward as one launch; 1 = not applicable, nothing enqueued
+int forward_pair_impl(const NetLayout& L, const float* params, const void* prep, const float* const x[3], float* ws_p,
+                      const HeadOut& out_p, const SlotSave* sv, float* const* sv_act, const float* tparams,
+                      const void* tprep, const float* const xt[3], float* ws_t, const HeadOut& out_t, int64_t B,
+                      int64_t Bp, hipStream_t st);
 int forward_impl(const NetLayout& L, const float* params, const void* prep, const float* const x[3], int64_t B,
                  int64_t Bp, float* ws, const HeadOut& out, const SlotSave* sv, float* const* sv_act, hipStream_t st,
                  void* ev_encoders_done);

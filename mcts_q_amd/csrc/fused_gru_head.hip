@@ -33,13 +33,12 @@ struct FusedLds {
 };
 
 template <bool SAVE>
-__global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadArgs ha) {
-    __shared__ __attribute__((aligned(16))) FusedLds L;
+__device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga, const HeadArgs& ha, int tile) {
     // the wave index (and everything derived from it: group, unit block, head tile) lives in scalar registers
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3, gtid = tid & 255;
     const int jl = lane & 15, q = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * TILE;
+    const int64_t row0 = (int64_t)tile * TILE;
     GruLds& G = L.g[grp];
     // group 0 takes the longest window; group 1 runs the other two back to back on the same SIMDs (issue
     // priorities were measured to make no difference: the two waves of a SIMD share it evenly)
@@ -112,6 +111,23 @@ __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadA
 #endif
 }
 
+template <bool SAVE>
+__global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadArgs ha) {
+    __shared__ __attribute__((aligned(16))) FusedLds L;
+    gru3_head_tile<SAVE>(L, ga, ha, blockIdx.x);
+}
+
+// The learner's two forwards in ONE launch: workgroups [0, n0) run the policy network on s with the activation records
+// kept, the others the target network on s' (dqn_per.py:455-463).  Same code per tile as the two separate launches;
+// what goes away is the second launch, the helper-stream hand-off around it and the cross-queue wait before the head
+// backward.
+__global__ __launch_bounds__(512) void gru3_head_fwd_pair_kernel(GruFwdArgs ga0, HeadArgs ha0, GruFwdArgs ga1, HeadArgs ha1,
+                                                                 int n0) {
+    __shared__ __attribute__((aligned(16))) FusedLds L;
+    if ((int)blockIdx.x < n0) gru3_head_tile<true>(L, ga0, ha0, blockIdx.x);
+    else gru3_head_tile<false>(L, ga1, ha1, (int)blockIdx.x - n0);
+}
+
 #ifdef MCTSQ_STAMPS
 extern "C" int mctsq_debug_stamps(long long* host_out) {
     (void)hipMemcpyFromSymbol(host_out + 64, HIP_SYMBOL(g_iter), sizeof(long long) * 192);
@@ -135,6 +151,18 @@ int launch_gru3_head_fwd(const GruFwdArgs& ga, const HeadArgs& ha, bool save, hi
     dim3 grid((unsigned)(ga.Bp / TILE));
     if (save) hipLaunchKernelGGL(gru3_head_fwd_kernel<true>, grid, dim3(512), 0, st, ga, ha);
     else hipLaunchKernelGGL(gru3_head_fwd_kernel<false>, grid, dim3(512), 0, st, ga, ha);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gru3_head_fwd_pair(const GruFwdArgs& ga0, const HeadArgs& ha0, const GruFwdArgs& ga1, const HeadArgs& ha1,
+                              hipStream_t st) {
+    if (check_gru_args(ga0) || check_gru_args(ga1)) return -1;
+    MCTSQ_CHECK(fused_gru_head_applicable(ga0, ha0) && fused_gru_head_applicable(ga1, ha1) && ha0.wprep && ha1.wprep,
+                "paired forward needs gru/gru/gru, a 192-128-128-A head and prepared weights");
+    MCTSQ_CHECK(ga0.B > 0 && ga1.B > 0, "paired forward: empty batch");
+    const int n0 = (int)(ga0.Bp / TILE), n1 = (int)(ga1.Bp / TILE);
+    hipLaunchKernelGGL(gru3_head_fwd_pair_kernel, dim3((unsigned)(n0 + n1)), dim3(512), 0, st, ga0, ha0, ga1, ha1, n0);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

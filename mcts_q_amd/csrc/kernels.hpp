@@ -25,7 +25,8 @@ struct GruSlot {
     float* bw_g;                         // [S][tile][4 = d(pre-activation) r | z | n | n*r] lane-major blocks of 1024
     float* bw_dsc;                       // [S][Bp] d(score)
     float* bw_p;                         // [Bp][64] dfeat * xhat (LayerNorm weight gradient terms)
-    float* bw_aw;                        // [Bp/16][65] per-tile partials of the score Linear(64,1) gradient
+    float* bw_aw;                        // [workgroups][65] per-workgroup partials of the score Linear(64,1) gradient
+    float* bw_ln;                        // [workgroups][64] per-workgroup partials of the LayerNorm weight gradient
 };
 // element (row, unit) of step block t of a lane-major record with Bp rows
 inline __host__ __device__ int64_t gru_rec_index(int64_t t, int64_t Bp, int64_t row, int unit) {
@@ -148,5 +149,8 @@ bool fused_gru_head_applicable(const GruFwdArgs& ga, const HeadArgs& ha);
 constexpr int64_t HEAD_PREP_BYTES = (int64_t)(8 * 6 * 3 + 8 * 4 * 3 + 4 * 3) * 64 * 16;
 int launch_head_prepare(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st);
 int launch_gru3_head_fwd(const GruFwdArgs& ga, const HeadArgs& ha, bool save, hipStream_t st);
+// (ga0, ha0): activation-saving forward, (ga1, ha1): plain forward, as one launch (the learner's policy / target pair)
+int launch_gru3_head_fwd_pair(const GruFwdArgs& ga0, const HeadArgs& ha0, const GruFwdArgs& ga1, const HeadArgs& ha1,
+                              hipStream_t st);
 
 }  // namespace mctsq

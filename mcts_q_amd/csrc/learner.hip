@@ -7,6 +7,7 @@
 // dW = delta^T . input, done by one generic split-K MFMA kernel whose partials are reduced in a
 // fixed order (bitwise reproducible, no float atomics).
 #include "device_utils.hpp"
+#include <type_traits>
 #include "learner.hpp"
 #include "prepare_core.hpp"
 #ifndef EXP_BWD
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
 
     // ---- LayerNorm backward -> dpool -------------------------------------------------------
     float dpool[RPL], pooled[RPL], mrun[RPL], linv[RPL];
+    float dlnw = 0.0f;                     // LayerNorm weight gradient of unit j over this workgroup's rows
     {
         float dxh[RPL], xh[RPL], rs[RPL];
 #pragma unroll
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             const float df = args.dfeat[row * FEAT + s.out_col + j];
             xh[r] = (pooled[r] - st.z) * st.w;
             dxh[r] = df * lnw;
-            s.bw_p[row * E + j] = df * xh[r];
+            dlnw += df * xh[r];
             const float s1 = row16_sum(dxh[r]), s2 = row16_sum(dxh[r] * xh[r]);
             if (jl == 0) { L.red[0][wq][4 * q + r] = s1; L.red[1][wq][4 * q + r] = s2; }
         }
@@ -475,8 +477,18 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     float dhc[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) dhc[r] = 0.0f;
-    auto bptt_step = [&](int t, StepIn& cur) {
+    // LAST (a compile-time flag): step t == 0, whose hidden-state gradient nobody needs.  The step body has no
+    // data-dependent branch around its memory operations: the compiler's wait-count bookkeeping stays exact across the
+    // loop (with a conditional prefetch it fell back to waiting for ALL outstanding loads at the top of every iteration,
+    // i.e. for the records requested one step earlier - the full memory latency, every third step).
+    auto bptt_step = [&](int t, StepIn& cur, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const int buf = t & 1;
+        // this step's record moves to locals and the buffer's next occupant starts its trip at once (below step 3: a
+        // harmless re-read of record 0 into a buffer that is done): the longer the distance to its use, the less of
+        // the memory latency the step sees
+        const StepIn in = cur;
+        if constexpr (!LAST) fetch(cur, t >= 3 ? t - 3 : 0);
         float zs[RPL], dhs[RPL], dsc[RPL], at[RPL];
         // everything read from LDS first, so that no read has to queue behind this step's plane writes
         {
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             for (int r = 0; r < RPL; ++r) pe[r] = L.pe[t][4 * q + r];
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-                at[r] = fast_exp2(cur.sc[r] - mrun[r]) * linv[r];
+                at[r] = fast_exp2(in.sc[r] - mrun[r]) * linv[r];
                 dsc[r] = at[r] * (((pe[r].x + pe[r].y) + (pe[r].z + pe[r].w)) - Dd[r]);
             }
         }
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
             const int i = 4 * q + r;
-            const float rg = cur.rg[r], zg = cur.zg[r], ng = cur.ng[r], hn = cur.hn[r], hprev = cur.hprev[r];
+            const float rg = in.rg[r], zg = in.zg[r], ng = in.ng[r], hn = in.hn[r], hprev = in.hprev[r];
             daw = fmaf(dsc[r], hnext[r], daw); dab += dsc[r];
             const float dh = dhc[r] + at[r] * dpool[r] + dsc[r] * awj;
             const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
@@ -514,56 +526,77 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             }
             zs[r] = zg; dhs[r] = dh;
         }
-        hnext = cur.hprev;
+        hnext = in.hprev;
         {                                                      // d(pre-activation) record for the weight gradients
             float* gb = s.bw_g + ((((int64_t)t * ntile + tile) * 4) * 4 + wq) * 256 + lo4;
             store_rows<RPL>(gb, g0); store_rows<RPL>(gb + 1024, g1);
             store_rows<RPL>(gb + 2048, g2); store_rows<RPL>(gb + 3072, g3);
         }
-        if (t >= 3) fetch(cur, t - 3);                         // this buffer's next occupant starts its trip
-        if (t == 0) return;                                    // dh_{-1} is not needed
+        if constexpr (LAST) return;                            // dh_{-1} is not needed
         __syncthreads();
-        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         {
-            // Three accumulators, one K chunk each per half, their MFMAs issued round-robin so that consecutive
-            // instructions never depend on each other; the second half's nine fragments are requested from LDS
-            // before the first half's products start.
+            // Two accumulators (even / odd K chunks) issued alternately, the next pair of chunks requested from LDS
+            // while the current pair multiplies: 12 fragment registers in use + 12 in flight.  (Three accumulators with
+            // nine + nine fragments measured the same per step but cost 24 more registers, and at that pressure the
+            // record prefetch below stalls on register reuse.)
             const int o = (lane & 15) * GPL + 8 * q;
-            u32x4 xa[3][3], xb[3][3];                         // [chunk of the half][plane]
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xa[c][pl] = *reinterpret_cast<const u32x4*>(&L.gp[buf][pl][o + 32 * (2 * c)]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xb[c][pl] = *reinterpret_cast<const u32x4*>(&L.gp[buf][pl][o + 32 * (2 * c + 1)]);
-            __builtin_amdgcn_sched_barrier(0);
+            u32x4 xa[2][3], xb[2][3];
+#define GB_LOAD(X, C0)                                                                              \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                      \
+                X[0][pl] = *reinterpret_cast<const u32x4*>(&L.gp[buf][pl][o + 32 * (C0)]);          \
+                X[1][pl] = *reinterpret_cast<const u32x4*>(&L.gp[buf][pl][o + 32 * ((C0) + 1)]);    \
+            }
             // cross terms smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); x plane / w plane
-#define GB_TERM(X, CH, XP, WP)                                                                     \
-            acc0 = mfma_bf(X[0][XP], wt[0 + CH][WP], acc0);                                        \
-            acc1 = mfma_bf(X[1][XP], wt[2 + CH][WP], acc1);                                        \
-            acc2 = mfma_bf(X[2][XP], wt[4 + CH][WP], acc2);
-            GB_TERM(xa, 0, 2, 0) GB_TERM(xa, 0, 0, 2) GB_TERM(xa, 0, 1, 1)
-            GB_TERM(xa, 0, 1, 0) GB_TERM(xa, 0, 0, 1) GB_TERM(xa, 0, 0, 0)
-            GB_TERM(xb, 1, 2, 0) GB_TERM(xb, 1, 0, 2) GB_TERM(xb, 1, 1, 1)
-            GB_TERM(xb, 1, 1, 0) GB_TERM(xb, 1, 0, 1) GB_TERM(xb, 1, 0, 0)
+#define GB_TERM(X, C0, XP, WP)                                                                      \
+            acc0 = mfma_bf(X[0][XP], wt[(C0)][WP], acc0);                                           \
+            acc1 = mfma_bf(X[1][XP], wt[(C0) + 1][WP], acc1);
+#define GB_PAIR(X, C0)                                                                              \
+            GB_TERM(X, C0, 2, 0) GB_TERM(X, C0, 0, 2) GB_TERM(X, C0, 1, 1)                          \
+            GB_TERM(X, C0, 1, 0) GB_TERM(X, C0, 0, 1) GB_TERM(X, C0, 0, 0)
+            GB_LOAD(xa, 0)
+            GB_LOAD(xb, 2)
+            GB_PAIR(xa, 0)
+            GB_LOAD(xa, 4)
+            GB_PAIR(xb, 2)
+            GB_PAIR(xa, 4)
+#undef GB_PAIR
 #undef GB_TERM
+#undef GB_LOAD
         }
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            dhc[r] = dhs[r] * zs[r] + ((acc0[r] + acc1[r]) + acc2[r]);
+            dhc[r] = dhs[r] * zs[r] + (acc0[r] + acc1[r]);
         }
     };
-    for (int t = S - 1; t >= 0; t -= 3) {                      // unrolled by three: the buffers keep their roles
-        bptt_step(t, sb0);
-        if (t >= 1) bptt_step(t - 1, sb1);
-        if (t >= 2) bptt_step(t - 2, sb2);
+    {
+        using No = std::integral_constant<bool, false>;
+        using Yes = std::integral_constant<bool, true>;
+        // steps S-1 .. 1 in groups of three (the buffers keep their roles), the (S-1) % 3 odd ones first, then step 0
+        int t = S - 1;
+        const int rem = t % 3;
+        if (rem == 1) {
+            bptt_step(t, sb0, No{});
+            StepIn x = sb0; sb0 = sb1; sb1 = sb2; sb2 = x;
+            t -= 1;
+        } else if (rem == 2) {
+            bptt_step(t, sb0, No{});
+            bptt_step(t - 1, sb1, No{});
+            StepIn x = sb2; sb2 = sb1; sb1 = sb0; sb0 = x;
+            t -= 2;
+        }
+        for (; t >= 3; t -= 3) {
+            bptt_step(t, sb0, No{});
+            bptt_step(t - 1, sb1, No{});
+            bptt_step(t - 2, sb2, No{});
+        }
+        bptt_step(0, sb0, Yes{});
     }
     daw += __shfl_xor(daw, 16, 64); daw += __shfl_xor(daw, 32, 64);
     dab += __shfl_xor(dab, 16, 64); dab += __shfl_xor(dab, 32, 64);
+    dlnw += __shfl_xor(dlnw, 16, 64); dlnw += __shfl_xor(dlnw, 32, 64);
     float* pa = s.bw_aw + (int64_t)hb * 65;                    // one partial per workgroup: [Bp/16 * NH][65]
-    if (q == 0) pa[j] = daw;
+    if (q == 0) { pa[j] = daw; s.bw_ln[(int64_t)hb * E + j] = dlnw; }
     if (wq == 0 && lane == 0) pa[64] = dab;
 }
 

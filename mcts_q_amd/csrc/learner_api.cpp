@@ -30,7 +30,7 @@ struct Carver {
 struct SlotPlan {                      // float offsets; which fields are used depends on the kind
     int64_t score, stat, pool, x, dsc, p;
     int64_t h, r, z, n, hn, g;          // gru
-    int64_t wp_ih, wp_rz, wp_n, wp_aw;  // gru: partials of the fused weight-gradient kernel / of gru_bwd_kernel
+    int64_t wp_ih, wp_rz, wp_n, wp_aw, wp_ln;  // gru: partials of the fused weight-gradient kernel / of gru_bwd_kernel
     int64_t wt;                         // gru: W_hh as split-bf16 B fragments of the BPTT product (gru_prepare_bwd_kernel)
     int gw_rows, gw_nsplit;
     int64_t c_h1, c_h2, c_d2, c_d1;     // conv
@@ -95,6 +95,7 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
             g.wp_rz = c.take((int64_t)g.gw_nsplit * (128 * E + 128));
             g.wp_n = c.take((int64_t)g.gw_nsplit * (E * E + E));
             g.wp_aw = c.take(Bp / TILE * 2 * 65);       // per workgroup of the GRU backward (8- or 16-sample tiles)
+            g.wp_ln = c.take(Bp / TILE * 2 * E);
             g.wt = c.take(GRU_PREP_BYTES / (int64_t)sizeof(float));
             pf += 2 * job_partial_floats(E, 0, Bp);
         } else if (e.kind == MCTSQ_ENC_CONV) {
@@ -196,7 +197,10 @@ namespace {
 // also legal under stream capture).  One helper stream and event set per (device, caller stream), created on first
 // use and kept for the life of the process, so calls on different streams never share events; calls on the SAME
 // stream are ordered by the caller (one host thread enqueues on a stream at a time).
-struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr, head = nullptr, join2 = nullptr, upd = nullptr; };
+struct SideStream {
+    hipStream_t st = nullptr, st2 = nullptr;               // helper lanes: encoder backward of the short windows; head products
+    hipEvent_t fork = nullptr, join = nullptr, head = nullptr, join2 = nullptr, join3 = nullptr, upd = nullptr;
+};
 std::mutex g_side_mu;
 std::map<std::pair<int, void*>, SideStream> g_side;
 int side_stream(hipStream_t caller, SideStream* out) {
@@ -206,6 +210,8 @@ int side_stream(hipStream_t caller, SideStream* out) {
     SideStream& s = g_side[std::make_pair(dev, (void*)caller)];
     if (!s.st) {
         MCTSQ_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        MCTSQ_HIP(hipStreamCreateWithFlags(&s.st2, hipStreamNonBlocking));
+        MCTSQ_HIP(hipEventCreateWithFlags(&s.join3, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.head, hipEventDisableTiming));
@@ -341,9 +347,11 @@ static int dqn_grad_entry(const mctsq_net_desc* net, const DqnPrep* pp, const fl
     const int rc = dqn_grad_enqueue(L, P, &side, pp, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice,
                                     d_nprocess, d_ngas, d_act, d_rew, d_done, d_isw, gamma, loss_scale, B, d_grad,
                                     d_loss, d_abs_td, d_qsa, d_target, d_sumsq_parts, upd, (float*)d_ws, st);
-    if (rc < 0) {                      // whatever was enqueued on the helper stream is joined back before returning
+    if (rc < 0) {                      // whatever was enqueued on the helper streams is joined back before returning
         (void)hipEventRecord(side.join2, side.st);
         (void)hipStreamWaitEvent(st, side.join2, 0);
+        (void)hipEventRecord(side.join3, side.st2);
+        (void)hipStreamWaitEvent(st, side.join3, 0);
     }
     // success: the helper lane was joined before the reduction; only the priority write-back (upd) may still be running
     // there - its caller (mctsq_per_dqn_step) joins it at the end of the step, behind the optimizer
@@ -428,13 +436,16 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
                 if (L.enc[s].kind == MCTSQ_ENC_GRU) { whh[n] = d_params + L.enc[s].gru.whh; wt[n] = ws + P.slot[s].wt; ++n; }
             if (launch_gru_prepare_bwd(whh, n, wt, side->st)) return -1;
         }
-        const float* x[3] = {d_nprice, d_nprocess, d_ngas};
-        HeadOut out{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
-        if (forward_impl(L, d_target_params, pp ? pp->target : nullptr, x, B, Bp, ws + P.feats_t, out, nullptr, nullptr,
+    }
+    const float* xn[3] = {d_nprice, d_nprocess, d_ngas};
+    const HeadOut out_t{ws + P.q_t, ws + P.qnext, nullptr, nullptr};
+    auto target_forward_on_helper = [&]() -> int {
+        if (forward_impl(L, d_target_params, pp ? pp->target : nullptr, xn, B, Bp, ws + P.feats_t, out_t, nullptr, nullptr,
                          side->st, nullptr))
             return -1;
         MCTSQ_HIP(hipEventRecord(side->join, side->st));
-    }
+        return 0;
+    };
     // 2. policy network on s, activations kept (dqn_per.py:455-457)
     SlotSave sv[3];
     memset(sv, 0, sizeof(sv));
@@ -444,7 +455,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         v.score = ws + g.score; v.stat = ws + g.stat; v.pool = ws + g.pool; v.x = ws + g.x; v.dsc = ws + g.dsc;
         v.p = ws + g.p;
         v.h = ws + g.h; v.r = ws + g.r; v.z = ws + g.z; v.n = ws + g.n; v.hn = ws + g.hn; v.g = ws + g.g;
-        v.aw = ws + g.wp_aw;
+        v.aw = ws + g.wp_aw; v.ln = ws + g.wp_ln;
         v.c_h1 = ws + g.c_h1; v.c_h2 = ws + g.c_h2; v.c_d2 = ws + g.c_d2; v.c_d1 = ws + g.c_d1;
         v.m_x = ws + g.m_x; v.m_m0 = ws + g.m_m0; v.m_d1 = ws + g.m_d1; v.m_d0 = ws + g.m_d0;
         if (L.enc[s].kind == MCTSQ_ENC_TRANSFORMER) {
@@ -466,13 +477,21 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     for (int i = 0; i + 1 < L.n_fc; ++i) sv_act[i] = ws + P.act[i];
     const float* xs[3] = {d_sprice, d_sprocess, d_sgas};
     {
-        HeadOut out{ws + P.q_p, nullptr, nullptr, nullptr};
-        if (forward_impl(L, d_params, pp ? pp->policy : nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr))
-            return -1;
+        // both forwards as ONE launch on the caller's stream when the network has the fused kernel and the weights are
+        // prepared; otherwise the target forward runs on the helper stream next to the policy forward
+        const HeadOut out{ws + P.q_p, nullptr, nullptr, nullptr};
+        const int pr = forward_pair_impl(L, d_params, pp ? pp->policy : nullptr, xs, ws + P.feats_p, out, sv, sv_act,
+                                         d_target_params, pp ? pp->target : nullptr, xn, ws + P.feats_t, out_t, B, Bp, st);
+        if (pr < 0) return -1;
+        if (pr == 1) {
+            if (target_forward_on_helper()) return -1;
+            if (forward_impl(L, d_params, pp ? pp->policy : nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr))
+                return -1;
+            MCTSQ_HIP(hipStreamWaitEvent(st, side->join, 0));
+        }
     }
     // 3. TD target, IS-weighted MSE, dLoss/dQ, new priorities (dqn_per.py:464-467, 474): evaluated in the prologue
     //    of the split-bf16 head backward (one launch fewer), or by its own kernel for other head shapes
-    MCTSQ_HIP(hipStreamWaitEvent(st, side->join, 0));
     TdArgs td;
     memset(&td, 0, sizeof(td));
     td.q = ws + P.q_p; td.qnext = ws + P.qnext; td.act = d_act; td.rew = d_rew; td.done = d_done; td.isw = d_isw;
@@ -599,10 +618,10 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             // attention score Linear(64,1): d(score) x h_t, per-tile partials written by gru_bwd_kernel
             if (jbB.add_external(g.wp_aw - P.partials, 1, E, (int)(Bp / TILE) * (gru_half[s == long_slot ? 0 : 1] ? 2 : 1),
                                  e.gru.aw, E, 1, e.gru.ab)) return -1;
-            // LayerNorm weight / bias: column sums over the batch
-            // (dfeat * xhat is written by this slot's backward: a short window's runs on the helper stream, ahead of jbA)
-            if (s == long_slot) { if (addB(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1; }
-            else if (addA(ws + g.p, E, 0, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnw)) return -1;
+            // LayerNorm weight: per-workgroup column sums of dfeat * xhat written by gru_bwd_kernel (a launch of its own
+            // for the long window's sums sat on the critical path); bias: column sums of dfeat over the batch
+            if (jbB.add_external(g.wp_ln - P.partials, E, 0, (int)(Bp / TILE) * (gru_half[s == long_slot ? 0 : 1] ? 2 : 1),
+                                 -1, 0, 0, e.gru.lnw)) return -1;
             if (addA(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
         } else if (e.kind == MCTSQ_ENC_CONV) {
             // conv weights [out][in][3]: one contraction per tap against the time-shifted input
@@ -651,25 +670,28 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             return -1;
     }
     MCTSQ_CHECK(part_pos <= P.partial_floats, "internal: partial buffer plan mismatch");
-    // helper stream: the head's products, then the short windows' weight gradients (their backward is already queued)
+    // second helper lane: what needs nothing but the head backward - the head's weight-gradient products and bias /
+    // LayerNorm-bias sums (15 us of latency-bound split-K launches), then the priority write-back.  On the first helper
+    // lane they sat behind the short windows' backward and made that lane the longest of the three.
+    MCTSQ_HIP(hipStreamWaitEvent(side->st2, side->head, 0));
     for (int i = 0; i < jbA.nlists; ++i)
-        if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st)) return -1;
+        if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st2)) return -1;
+    MCTSQ_HIP(hipEventRecord(side->join3, side->st2));
+    if (upd) {                                                // joined by mctsq_per_dqn_step behind the optimizer
+        if (launch_per_update(upd->tree, upd->prio, upd->stamp, upd->cap, upd->head, upd->size, upd->idx, d_abs_td, B,
+                              upd->alpha, upd->mass_cap, side->st2))
+            return -1;
+        MCTSQ_HIP(hipEventRecord(side->upd, side->st2));
+    }
+    // first helper lane: the short windows' weight gradients (their backward is already queued there)
     if (launch_gru_wgrad(gwSide, side->st)) return -1;
     MCTSQ_HIP(hipEventRecord(side->join2, side->st));
-    // the priority write-back (needs only |td| of the head backward) goes LAST on the helper lane: it then runs next
-    // to the reduction on the caller's stream instead of ahead of the short windows' backward, where it sat on the
-    // path to join2 (the two lanes are balanced to a few microseconds); the caller's stream picks it up below
-    if (upd) {
-        if (launch_per_update(upd->tree, upd->prio, upd->stamp, upd->cap, upd->head, upd->size, upd->idx, d_abs_td, B,
-                              upd->alpha, upd->mass_cap, side->st))
-            return -1;
-        MCTSQ_HIP(hipEventRecord(side->upd, side->st));
-    }
     // caller's stream: the long window's weight gradients and everything else behind the encoder backward
     if (launch_gru_wgrad(gwMain, st)) return -1;
     for (int i = 0; i < jbB.nlists; ++i)
         if (launch_wgrad(jbB.lists[i], ws, ws + P.partials, st)) return -1;
     MCTSQ_HIP(hipStreamWaitEvent(st, side->join2, 0));
+    MCTSQ_HIP(hipStreamWaitEvent(st, side->join3, 0));
     // 7. ordered reduction of all partials into the flat gradient (+ the pieces of its norm, + the loss): the two
     // lanes' job lists are reduced by the same launches (40 jobs each)
     WJobList rl;
