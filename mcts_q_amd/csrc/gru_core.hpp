@@ -194,10 +194,17 @@ struct GruWave {
     }
     // training record of the staged window (time-major, 8 columns); call after the barrier
     __device__ __forceinline__ void save_window(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t Bp) {
-        const int S = s.S, sh = FP == 8 ? 3 : 2;
-        for (int idx = gtid; idx < TILE * S * 8; idx += 256) {
-            const int i = idx / (S * 8), rem = idx - i * (S * 8), t = rem >> 3, f = rem & 7;
-            s.sv_x[((int64_t)t * Bp + row0 + i) * 8 + f] = f < FP ? L.xs[i * XLD + (t << sh) + f] : 0.0f;
+        // sv_x[(t * Bp + row) * 8 + f]: one (step, row) pair per thread and pass, its eight floats as two 16-byte stores
+        // (index math is shifts only; the element-wise form divided by S * 8 thirteen times per thread)
+        const int n = TILE * s.S;
+        for (int idx = gtid; idx < n; idx += 256) {
+            const int t = idx >> 4, i = idx & 15;
+            const float* x = &L.xs[i * XLD + t * (FP == 8 ? 8 : 4)];
+            f32x4 a = {x[0], x[1], x[2], x[3]}, b = {0, 0, 0, 0};
+            if (FP == 8) b = (f32x4){x[4], x[5], x[6], x[7]};       // xs is zero padded up to FP features
+            float* dst = s.sv_x + ((int64_t)t * Bp + row0 + i) * 8;
+            *reinterpret_cast<f32x4*>(dst) = a;
+            *reinterpret_cast<f32x4*>(dst + 4) = b;
         }
     }
 
@@ -234,10 +241,14 @@ struct GruWave {
                                            int t, int64_t row0, int64_t Bp) {
         const float p[4][4] = {{sp[0].x, sp[0].y, sp[0].z, sp[0].w}, {sp[1].x, sp[1].y, sp[1].z, sp[1].w},
                                {sp[2].x, sp[2].y, sp[2].z, sp[2].w}, {sp[3].x, sp[3].y, sp[3].z, sp[3].w}};
+        if (SAVE) {                                           // the four rows' scores (log2 units) as one 16-byte store
+            const f32x4 sc4 = {(p[0][0] + p[1][0]) + (p[2][0] + p[3][0]), (p[0][1] + p[1][1]) + (p[2][1] + p[3][1]),
+                               (p[0][2] + p[1][2]) + (p[2][2] + p[3][2]), (p[0][3] + p[1][3]) + (p[2][3] + p[3][3])};
+            if (live && wq == 0 && jl == 0) *reinterpret_cast<f32x4*>(&s.sv_score[(int64_t)t * Bp + row0 + 4 * q]) = sc4;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float sc = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
-            if (SAVE && live && wq == 0 && jl == 0) s.sv_score[(int64_t)t * Bp + row0 + 4 * q + r] = sc;   // log2 units
             if (BND) {
                 const float e = fast_exp2(sc);
                 att[r] = fmaf(e, hv[r], att[r]);
@@ -392,10 +403,8 @@ struct GruWave {
             out[i * ld + j] = (pooled[r] - mean[r]) * rstd[r] * lnw + lnb;
             if (SAVE) {
                 s.sv_pool[(row0 + i) * (int64_t)E + j] = pooled[r];
-                if (wq == 0 && jl == 0) {
-                    float* st = s.sv_stat + (row0 + i) * 4;
-                    st[0] = mrun[r]; st[1] = lrun[r]; st[2] = mean[r]; st[3] = rstd[r];
-                }
+                if (wq == 0 && jl == 0)
+                    *reinterpret_cast<f32x4*>(s.sv_stat + (row0 + i) * 4) = (f32x4){mrun[r], lrun[r], mean[r], rstd[r]};
             }
         }
     }
@@ -424,10 +433,8 @@ struct GruWave {
             if (SAVE) {
                 if (gfeats) gfeats[(row0 + i) * (int64_t)FEAT + s.out_col + j] = v;
                 s.sv_pool[(row0 + i) * (int64_t)E + j] = pooled[r];
-                if (wq == 0 && jl == 0) {
-                    float* st = s.sv_stat + (row0 + i) * 4;
-                    st[0] = mrun[r]; st[1] = lrun[r]; st[2] = mean[r]; st[3] = rstd[r];
-                }
+                if (wq == 0 && jl == 0)
+                    *reinterpret_cast<f32x4*>(s.sv_stat + (row0 + i) * 4) = (f32x4){mrun[r], lrun[r], mean[r], rstd[r]};
             }
         }
     }
