@@ -920,7 +920,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const fl
         const float* p = partials + J.part_off + le;
         float acc = 0.0f;
         int sp = 0;
-        for (; sp + 8 <= J.nsplit; sp += 8) {                 // eight loads in flight, summed in split order
+        // summed in split order; 32 (then 8) loads in flight: the chain of dependent round trips, not the bytes, is what
+        // this kernel costs (160 partials per element of the long window's gradients: 20 rounds of eight took 12 us)
+        for (; sp + 32 <= J.nsplit; sp += 32) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = p[(int64_t)(sp + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += v[u];
+        }
+        for (; sp + 8 <= J.nsplit; sp += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(sp + u) * stride];
