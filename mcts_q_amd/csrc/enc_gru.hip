@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void gru_enc_fwd_kernel(GruFwdArgs args) {
     __syncthreads();
     if (SAVE) g.save_window(s, L, threadIdx.x, row0, args.Bp);
     g.run(s, L, row0, args.Bp);
-    g.fin0(L);
+    g.fin0(L, s, row0);
     g.sync(L);
     g.fin2(s, L, args.feats + row0 * FEAT + s.out_col, FEAT, row0, g.lnwj, g.lnbj);
 }

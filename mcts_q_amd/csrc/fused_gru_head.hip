@@ -75,7 +75,7 @@ __device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga
         // LayerNorm (init_weights touches none of its inputs)
         g.stage_issue(ga.slot[sn], gtid, row0, ga.B);
         g.init_weights(ga.slot[sn]);
-        g.fin0(G);
+        g.fin0(G, s, row0);
         g.sync(G);
         g.fin2_split(s, G, &L.head.fpl[0][0], TILE * FPL, FPL, row0, lnw, lnb, SAVE ? ga.feats : nullptr);
         WSTAMP(wi, 4);
@@ -94,7 +94,7 @@ __device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga
     {
         const GruSlot& s = ga.slot[si];
         WSTAMP(nwin - 1, 5);
-        g.fin0(G);
+        g.fin0(G, s, row0);
         g.sync(G);
         g.fin2_split(s, G, &L.head.fpl[0][0], TILE * FPL, FPL, row0, g.lnwj, g.lnbj, SAVE ? ga.feats : nullptr);
         WSTAMP(nwin - 1, 4);

@@ -377,10 +377,18 @@ struct GruWave {
     // LayerNorm over the 64 hidden units (4 waves x 16 lanes) with ONE group sync: every wave publishes the
     // sum and the centred sum of squares of its 16 units, and the four pairs are merged exactly
     // (M2 = sum M2_w + 16 sum (mean_w - mean)^2) -- the accuracy of the two-pass form without its second sync.
-    __device__ __forceinline__ void fin0(GruLds& L) {
+    // s, row0: for the training record.  The softmax statistics and the pooled vector leave for global memory HERE,
+    // where they are last used, not in fin2: kept alive across the sync they cost register spills whose reloads sat
+    // in the middle of the LayerNorm (scratch round trips: ~4 us per window in the saving kernel).
+    __device__ __forceinline__ void fin0(GruLds& L, const GruSlot& s, int64_t row0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             pooled[r] = att[r] / lrun[r];
+            if (SAVE) {                                       // uniform base (scalar registers) + 32-bit lane offset
+                const int i = 4 * q + r;
+                (s.sv_pool + row0 * (int64_t)E)[(unsigned)(i * E + j)] = pooled[r];
+                if (wq == 0 && jl == 0) *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(i * 4)) = (f32x2){mrun[r], lrun[r]};
+            }
             const float ssum = row16_sum(pooled[r]);
             const float d = pooled[r] - ssum * (1.0f / 16);
             const float m2 = row16_sum(d * d);
@@ -401,11 +409,8 @@ struct GruWave {
                              16.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             rstd[r] = 1.0f / sqrtf(m2 * (1.0f / E) + LN_EPS);
             out[i * ld + j] = (pooled[r] - mean[r]) * rstd[r] * lnw + lnb;
-            if (SAVE) {
-                s.sv_pool[(row0 + i) * (int64_t)E + j] = pooled[r];
-                if (wq == 0 && jl == 0)
-                    *reinterpret_cast<f32x4*>(s.sv_stat + (row0 + i) * 4) = (f32x4){mrun[r], lrun[r], mean[r], rstd[r]};
-            }
+            if (SAVE && wq == 0 && jl == 0)
+                *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(i * 4 + 2)) = (f32x2){mean[r], rstd[r]};
         }
     }
     // fin2 for a consumer that multiplies on the bf16 matrix instruction: the normalised feature goes to three
@@ -431,10 +436,8 @@ struct GruWave {
             dst[pstride] = (unsigned short)(u1 >> 16);
             dst[2 * pstride] = (unsigned short)(u2 >> 16);
             if (SAVE) {
-                if (gfeats) gfeats[(row0 + i) * (int64_t)FEAT + s.out_col + j] = v;
-                s.sv_pool[(row0 + i) * (int64_t)E + j] = pooled[r];
-                if (wq == 0 && jl == 0)
-                    *reinterpret_cast<f32x4*>(s.sv_stat + (row0 + i) * 4) = (f32x4){mrun[r], lrun[r], mean[r], rstd[r]};
+                if (gfeats) (gfeats + row0 * (int64_t)FEAT)[(unsigned)(i * FEAT + j + s.out_col)] = v;
+                if (wq == 0 && jl == 0) *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(i * 4 + 2)) = (f32x2){mean[r], rstd[r]};
             }
         }
     }

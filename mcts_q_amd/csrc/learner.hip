@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     const int slot = blockIdx.x % args.nslots;
     const int hb = blockIdx.x / args.nslots;
     const int64_t tile = hb / NH;
-    const int rb = (hb % NH) * RPL;                            // first of this workgroup's rows within a lane's four
+    const int half = hb % NH;
     const int64_t row0 = tile * TILE;
     const GruSlot& s = args.slot[slot];
     const int lane = threadIdx.x & 63, wq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), jl = lane & 15, q = lane >> 4;
@@ -377,7 +377,13 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     const int64_t Bp = args.Bp;
     // lane-major records (kernels.hpp: GruSlot): block (t, tile, wave) is 256 floats, a lane's four rows one float4
     const int64_t ntile = Bp / TILE;
-    const int lo4 = lane * 4 + rb;
+    // Which samples a lane owns.  RPL == 4: rows 4q .. 4q+3, its whole float4 of a record.  RPL == 2: the workgroup owns the
+    // tile's rows 8*half .. 8*half+7 and lane (jl, q) rows 8*half + 2q + {0, 1}, i.e. one half of the float4 of record
+    // lane jl + 16 * (2*half + q/2): the wave's 64 lanes together read / write one contiguous 512-byte half of the
+    // record block (an interleaved split - rows 2*half + {0, 1} of every lane - made both workgroups of a tile touch
+    // every cache line: 128 MB of traffic per launch instead of 35).
+    const int rbase = RPL == 4 ? 4 * q : 8 * half + 2 * q;    // first owned row within the tile
+    const int lo4 = RPL == 4 ? lane * 4 : (jl + 16 * (2 * half + (q >> 1))) * 4 + 2 * (q & 1);
     auto rec = [&](const float* base, int t) {
         return load_rows<RPL>(base + (((int64_t)t * ntile + tile) * 4 + wq) * 256 + lo4);
     };
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         float dxh[RPL], xh[RPL], rs[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            const int64_t row = row0 + 4 * q + rb + r;
+            const int64_t row = row0 + rbase + r;
             const float4 st = *reinterpret_cast<const float4*>(s.sv_stat + row * 4);
             mrun[r] = st.x; linv[r] = 1.0f / st.y; rs[r] = st.w;
             pooled[r] = s.sv_pool[row * E + j];
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     // recurrence never waits on HBM/L2 latency.
     struct StepIn { RowVec<RPL> rg, zg, ng, hn, hprev, sc; };
     StepIn sb0, sb1, sb2;                  // three steps of saved activations in flight (HBM latency > one step)
-    const float* scp = s.sv_score + row0 + 4 * q + rb;
+    const float* scp = s.sv_score + row0 + rbase;
     auto fetch = [&](StepIn& d, int t) {
         d.rg = rec(s.sv_r, t); d.zg = rec(s.sv_z, t); d.ng = rec(s.sv_n, t); d.hn = rec(s.sv_hn, t);
         d.hprev = rec(s.sv_h, t);                              // block t = h_{t-1}
