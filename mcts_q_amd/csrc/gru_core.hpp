@@ -345,6 +345,17 @@ struct GruWave {
             rg[r] = sigmoid_fast(accr[r]);
             zg[r] = sigmoid_fast(accz[r]);
         }
+        // training record, lane-major (kernels.hpp: GruSlot): the lane's four rows of one unit are one 16-byte store, a
+        // wave's store instruction one contiguous KB.  Uniform 64-bit base (scalar registers) + 32-bit lane offset: no
+        // vector address math.  Each field leaves as soon as it exists (r, z here, under the n gate's products; n, W_hn h
+        // and h at the end): five stores back to back from every wave of the CU at once queued up in the memory pipe
+        // and the last wave's issue stalled behind them on the step's critical path.
+        const int64_t ub = SAVE ? (((int64_t)t * (Bp / TILE) + row0 / TILE) * 4 + wq) * 256 : 0;
+        const int lo = lane * 4;
+        if (SAVE) {
+            *reinterpret_cast<f32x4*>(s.sv_r + ub + lo) = (f32x4){rg[0], rg[1], rg[2], rg[3]};
+            *reinterpret_cast<f32x4*>(s.sv_z + ub + lo) = (f32x4){zg[0], zg[1], zg[2], zg[3]};
+        }
         f32x4 svn, svhn, svh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -361,13 +372,6 @@ struct GruWave {
             hh[cur][r] = hnew;
         }
         if (SAVE) {
-            // training record, lane-major (kernels.hpp: GruSlot): the lane's four rows of one unit are one 16-byte
-            // store, a wave's store instruction one contiguous KB.  Uniform 64-bit base (scalar registers) + 32-bit
-            // lane offset: no vector address math
-            const int64_t ub = (((int64_t)t * (Bp / TILE) + row0 / TILE) * 4 + wq) * 256;
-            const int lo = lane * 4;
-            *reinterpret_cast<f32x4*>(s.sv_r + ub + lo) = (f32x4){rg[0], rg[1], rg[2], rg[3]};
-            *reinterpret_cast<f32x4*>(s.sv_z + ub + lo) = (f32x4){zg[0], zg[1], zg[2], zg[3]};
             *reinterpret_cast<f32x4*>(s.sv_n + ub + lo) = svn;
             *reinterpret_cast<f32x4*>(s.sv_hn + ub + lo) = svhn;
             *reinterpret_cast<f32x4*>(s.sv_h + ub + Bp * E + lo) = svh;
