@@ -124,8 +124,8 @@ int mctsq_encoder_forward(const mctsq_encoder_desc* enc, const float* d_enc_para
  *   d_qsa [B] and d_target [B] fp32 (optional, may be NULL).
  * loss_scale: multiplies the loss AND its gradient.  Data-parallel: pass B_local / B_global on every rank and
  * all-reduce(SUM) gradient and loss - both then are those of the global batch mean; else 1.
- * Besides `stream`, the call uses one helper stream per (device, stream), forked from and joined back to
- * `stream` with events inside the call (also on every error path). */
+ * Besides `stream`, the call uses two helper streams the library keeps per (device, stream), forked from and joined
+ * back to `stream` with events inside the call (also on every error path). */
 int64_t mctsq_dqn_grad_workspace_bytes(const mctsq_net_desc* net, int64_t B);
 int mctsq_dqn_grad(const mctsq_net_desc* net, const float* d_params, const float* d_target_params,
                    const float* d_sprice, const float* d_sprocess, const float* d_sgas,
