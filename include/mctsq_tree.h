@@ -126,7 +126,7 @@ void mctsq_lockstep_backup(mctsq_forest* f, int64_t k_lo, int64_t k_hi, const in
 typedef struct {
     void *forward, *event_record, *event_sync, *memcpy_async;
     const void *net, *params, *prep;
-    void* stream;
+    void* stream[4];            /* one stream per block: the blocks' leaf batches (a few CUs each) then overlap on the device */
     int64_t halves, cap, ws_bytes, n_act;
     float *stage[4], *dev_in[4], *q[4], *vmax[4], *prior[4];
     int32_t* argmax[4];

@@ -38,6 +38,21 @@ double mctsq_lockstep_uniform(uint64_t seed, uint64_t iteration, uint64_t k, uin
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+/* c_puct(tv) = log((1 + tv + c_base) / c_base) + c_init and sqrt(tv) for tv < PUCT_TAB, tabulated with the very
+ * expressions of the walk below (same bits), rebuilt when (c_base, c_init) change: a logarithm and a square root per
+ * level and tree were half of the selection's arithmetic.  One table per process, filled by the calling thread before
+ * the parallel region (the search driver is single-threaded). */
+#define PUCT_TAB 8192
+static double g_puct[PUCT_TAB], g_sqrt[PUCT_TAB], g_tab_base = -1.0, g_tab_init = -1.0;
+static void puct_table(double c_base, double c_init) {
+    if (g_tab_base == c_base && g_tab_init == c_init) return;
+    for (int64_t tv = 0; tv < PUCT_TAB; ++tv) {
+        g_puct[tv] = log((1.0 + (double)tv + c_base) / c_base) + c_init;
+        g_sqrt[tv] = sqrt((double)tv);
+    }
+    g_tab_base = c_base; g_tab_init = c_init;
+}
+
 static inline int64_t select_leaf(const mctsq_forest* f, int64_t cur, int64_t maxd, double c_base, double c_init) {
     for (;;) {
         if (f->done[cur] || f->depth[cur] >= maxd || f->tried[cur] != f->legal[cur]) return cur;
@@ -45,8 +60,8 @@ static inline int64_t select_leaf(const mctsq_forest* f, int64_t cur, int64_t ma
         int64_t tv = 0;
         for (int a = 0; a < N_ACT; ++a)
             if (ch[a] >= 0) tv += f->visits[ch[a]];
-        const double c_puct = log((1.0 + (double)tv + c_base) / c_base) + c_init;
-        const double sq = sqrt((double)tv);
+        const double c_puct = tv < PUCT_TAB ? g_puct[tv] : log((1.0 + (double)tv + c_base) / c_base) + c_init;
+        const double sq = tv < PUCT_TAB ? g_sqrt[tv] : sqrt((double)tv);
         double best = -INFINITY;
         int64_t pick = -1;
         for (int a = 0; a < N_ACT; ++a) {
@@ -69,6 +84,7 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
     const int64_t nk = k_hi - k_lo, D = f->D, W = f->row_w, P = W - 6 - (D - MCTSQ_PTG_STATE_HEAD);
     const int64_t L6 = D - MCTSQ_PTG_STATE_HEAD;
     if (nk <= 0) return 0;
+    puct_table(c_base, c_init);
     /* ONE parallel region, one barrier: every thread owns a contiguous run of trees, selects for it and counts its
        expansions; after the barrier it knows its first slot (prefix over the threads' counts), so slots - and with
        them node ids - are in tree order whatever the thread count */
@@ -224,12 +240,12 @@ int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, do
                 int e = 0;
                 if (ev->dev_in[h]) {
                     in = ev->dev_in[h];
-                    e = copy(ev->dev_in[h], ev->stage[h], sizeof(float) * (size_t)(cap * f->row_w), 1, ev->stream);
+                    e = copy(ev->dev_in[h], ev->stage[h], sizeof(float) * (size_t)(cap * f->row_w), 1, ev->stream[h]);
                 }
                 if (!e)
                     e = forward(ev->net, ev->params, ev->prep, in, in + cap * P, in + cap * (P + L6), n_new, ev->q[h],
-                                ev->vmax[h], ev->argmax[h], ev->prior[h], ev->ws[h], ev->ws_bytes, ev->stream, NULL);
-                if (!e) e = ev_record(ev->event[h], ev->stream);
+                                ev->vmax[h], ev->argmax[h], ev->prior[h], ev->ws[h], ev->ws_bytes, ev->stream[h], NULL);
+                if (!e) e = ev_record(ev->event[h], ev->stream[h]);
                 if (e) { rc = -1000 - (e < 0 ? -e : e); break; }
             }
             pend[h] = n_new;

@@ -98,6 +98,10 @@ class DeviceLeafEvaluator:
         self._q = [torch.empty(cap, A, dtype=torch.float32, device=dev) for _ in range(halves)]
         self._arg = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(halves)]
         self._ev = [torch.cuda.Event() for _ in range(halves)]
+        # one stream per block: a block's leaf batch covers a few CUs and takes the kernel's full latency whatever its
+        # size, so the blocks' launches are worth overlapping on the device, not only with the host
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(halves)]
+        self._ready = torch.cuda.Event()
         nbytes = lib.check(lib.mctsq_q_forward_workspace_bytes(C.byref(net.desc), cap))
         self._ws = [torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev) for _ in range(halves)]
         self._args = None
@@ -109,10 +113,12 @@ class DeviceLeafEvaluator:
         """Bind the pointers of one search: the weights do not change inside predict()."""
         net, C, ptr, cap = self.net, self._C, self._ptr, self.cap
         self._stream = torch.cuda.current_stream(net.device)
-        st = self._stream.cuda_stream
         prep = ptr(net._prepared())
+        self._ready.record(self._stream)              # weights (and their prepared fragments) as of the caller's stream
         self._args = []
         for h in range(self.halves):
+            self._streams[h].wait_event(self._ready)
+            st = self._streams[h].cuda_stream
             src = self._hin[h] if self.zero_copy else self._din[h]
             base = src.data_ptr()
             self._args.append((C.byref(net.desc), ptr(net.flat), prep, base, base + 4 * cap * 25, base + 4 * cap * 85,
@@ -134,9 +140,9 @@ class DeviceLeafEvaluator:
         le.event_sync, le.memcpy_async = addr(hip.hipEventSynchronize), addr(hip.hipMemcpyAsync)
         a = self._args[0]
         le.net, le.params, le.prep = C.addressof(self.net.desc), a[1], a[2]
-        le.stream = self._stream.cuda_stream
         le.halves, le.cap, le.ws_bytes, le.n_act = self.halves, self.cap, self._ws[0].numel(), self.n_act
         for h in range(self.halves):
+            le.stream[h] = self._streams[h].cuda_stream
             le.stage[h] = self._hin[h].data_ptr()
             le.dev_in[h] = None if self.zero_copy else self._din[h].data_ptr()
             le.q[h], le.argmax[h], le.ws[h] = self._q[h].data_ptr(), self._arg[h].data_ptr(), self._ws[h].data_ptr()
@@ -157,11 +163,12 @@ class DeviceLeafEvaluator:
 
     def launch(self, h, n):
         a = self._args[h]
-        if not self.zero_copy:
-            self._din[h].copy_(self._hin[h], non_blocking=True)
-        self._lib.check(self._lib.mctsq_q_forward_prepared(a[0], a[1], a[2], a[3], a[4], a[5], n, a[6], a[7], a[8], a[9],
-                                                           a[10], a[11], a[12], a[13]))
-        self._ev[h].record(self._stream)
+        with torch.cuda.stream(self._streams[h]):
+            if not self.zero_copy:
+                self._din[h].copy_(self._hin[h], non_blocking=True)
+            self._lib.check(self._lib.mctsq_q_forward_prepared(a[0], a[1], a[2], a[3], a[4], a[5], n, a[6], a[7], a[8],
+                                                               a[9], a[10], a[11], a[12], a[13]))
+            self._ev[h].record(self._streams[h])
 
     def wait(self, h):
         self._ev[h].synchronize()

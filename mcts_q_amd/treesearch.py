@@ -79,7 +79,7 @@ class Forest(ctypes.Structure):
 class LeafEval(ctypes.Structure):
     """mctsq_leaf_eval (include/mctsq_tree.h): what mctsq_lockstep_search needs to launch and await leaf batches."""
     _fields_ = ([(k, ctypes.c_void_p) for k in ("forward", "event_record", "event_sync", "memcpy_async", "net", "params",
-                                                "prep", "stream")] +
+                                                "prep")] + [("stream", ctypes.c_void_p * 4)] +
                 [(k, ctypes.c_int64) for k in ("halves", "cap", "ws_bytes", "n_act")] +
                 [(k, ctypes.c_void_p * 4) for k in ("stage", "dev_in", "q", "vmax", "prior", "argmax", "ws", "event")])
 
