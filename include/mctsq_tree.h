@@ -10,6 +10,10 @@
 extern "C" {
 #endif
 
+/* threads used by the parallel loops of this library (MCTSQ_TREE_THREADS, else min(OpenMP default, CPUs of this process /
+ * LOCAL_WORLD_SIZE)) */
+int mctsq_tree_threads(void);
+
 /* Selection (replaces the walk of MCTSQ._select, src/mctsq_config_mcts_per.py:266-308, for K trees at once):
  * from root[k] descend to the child maximising  total/visits + c_puct * prior_a * sqrt(sum visits) / (1 + visits),
  * c_puct = log((1 + sum visits + c_base) / c_base) + c_init, first maximum in creation order, until a terminal node

@@ -14,17 +14,7 @@
 #define N_ACT 5
 static const int64_t LEGAL_OF_STATE[5] = {0x07, 0x07, 0x1B, 0x1B, 0x1B};     /* get_legal_actions (:524-546) */
 
-/* threads of the per-block loops: MCTSQ_TREE_THREADS if set (a block of a few hundred trees is ~10 us of work per
- * thread, so the fork / join cost of a wide team can outweigh it), else OpenMP's own default */
-static int tree_threads(void) {
-    static int n = -1;
-    if (n < 0) {
-        const char* e = getenv("MCTSQ_TREE_THREADS");
-        n = e ? atoi(e) : 0;
-        if (n <= 0) n = omp_get_max_threads();
-    }
-    return n;
-}
+#define tree_threads mctsq_tree_threads
 
 static inline uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;

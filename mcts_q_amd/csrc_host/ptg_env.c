@@ -420,7 +420,7 @@ int64_t mctsq_ptg_step(const void* env, int64_t n, const double* states, const i
     const Env* e = (const Env*)env;
     const int64_t D = e->D;
     int64_t bad = 0;
-#pragma omp parallel for schedule(static) reduction(+ : bad) if (n >= 128)
+#pragma omp parallel for schedule(static) reduction(+ : bad) if (n >= 128) num_threads(mctsq_tree_threads())
     for (int64_t s = 0; s < n; ++s)
         bad += step_one(e, states + s * D, actions[s], noise ? noise[s] : 0.0, next + s * D,
                         price ? price + s * ld_price : NULL, proc ? proc + s * ld_proc : NULL,

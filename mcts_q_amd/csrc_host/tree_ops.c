@@ -4,6 +4,9 @@
  * host cores.  Arithmetic and tie-breaking are those of the numpy path, which restates
  * mctsq_config_mcts_per.py:266-308 (select) and :358-381 (backup); tests/test_treesearch_cpu.py runs both paths
  * against each other.  Built by mcts_q_amd/csrc/Makefile into mcts_q_amd/lib/libmctsq_tree.so (gcc, no GPU code). */
+#define _GNU_SOURCE
+#include <sched.h>
+#include <omp.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -12,13 +15,38 @@
 
 #define N_ACT 5
 
+/* Threads of every parallel loop of this library: MCTSQ_TREE_THREADS if set; else OpenMP's default, capped by the CPUs
+ * this process may run on divided by the ranks sharing the node (LOCAL_WORLD_SIZE, set by torch.distributed.run).
+ * The loops are short (tens of microseconds) and the teams spin between them, so more threads than cores - e.g. 8 ranks
+ * x 16 threads on a 64-core share - does not merely waste time, it collapses (measured: 2 ranks x 16 threads on 16 CPUs
+ * ran the search 200x slower). */
+int mctsq_tree_threads(void) {
+    static int n = -1;
+    if (n < 0) {
+        const char* e = getenv("MCTSQ_TREE_THREADS");
+        int v = e ? atoi(e) : 0;
+        if (v <= 0) {
+            v = omp_get_max_threads();
+            cpu_set_t set;
+            int cpus = 0;
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+            const char* w = getenv("LOCAL_WORLD_SIZE");
+            const int ranks = w && atoi(w) > 0 ? atoi(w) : 1;
+            if (cpus > 0 && v > cpus / ranks) v = cpus / ranks;
+            if (v < 1) v = 1;
+        }
+        n = v;
+    }
+    return n;
+}
+
 /* cur_out[k] = the node selection stops at for tree k: a terminal node, a node at the depth limit, or the first
  * node with an untried legal action. */
 void mctsq_tree_select(int64_t K, const int64_t* root, int64_t maxd, double c_base, double c_init,
                        const uint8_t* done, const int64_t* depth, const int64_t* legal, const int64_t* tried,
                        const int64_t* child, const int64_t* visits, const double* total, const double* prior_a,
                        int64_t* cur_out) {
-#pragma omp parallel for schedule(static) if (K >= 256)
+#pragma omp parallel for schedule(static) if (K >= 256) num_threads(mctsq_tree_threads())
     for (int64_t k = 0; k < K; ++k) {
         int64_t cur = root[k];
         for (;;) {
@@ -51,7 +79,7 @@ void mctsq_tree_select(int64_t K, const int64_t* root, int64_t maxd, double c_ba
 /* every node on the path leaf -> root of tree k gains one visit and the leaf's value */
 void mctsq_tree_backup(int64_t K, const int64_t* leaf, const double* vmax, const int64_t* parent, int64_t* visits,
                        double* total) {
-#pragma omp parallel for schedule(static) if (K >= 256)
+#pragma omp parallel for schedule(static) if (K >= 256) num_threads(mctsq_tree_threads())
     for (int64_t k = 0; k < K; ++k) {
         int64_t node = leaf[k];
         if (node < 0) continue;
@@ -95,7 +123,7 @@ static void compact_wide(int64_t n, int64_t m, const int64_t* newid, int64_t* ol
             return;
         }
     }
-#pragma omp parallel if (moved >= 2048)
+#pragma omp parallel if (moved >= 2048) num_threads(mctsq_tree_threads())
     {
 #pragma omp for schedule(static)
         for (int64_t j = first; j < m; ++j) {

@@ -45,7 +45,7 @@ def test_host_tree_helper_exports_its_header():
     text = open(os.path.join(ROOT, "include", "mctsq_tree.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(mctsq_tree_[a-z0-9_]+)\s*\(", text)))
-    assert names == ["mctsq_tree_backup", "mctsq_tree_retain", "mctsq_tree_select"]
+    assert names == ["mctsq_tree_backup", "mctsq_tree_retain", "mctsq_tree_select", "mctsq_tree_threads"]
     dll = ctypes.CDLL(os.path.join(ROOT, "mcts_q_amd", "lib", "libmctsq_tree.so"))
     assert all(hasattr(dll, n) for n in names)
     env = sorted(set(re.findall(r"\b(mctsq_ptg_[a-z0-9_]+)\s*\(", text)))
