@@ -310,6 +310,9 @@ def test_one_call_step_equals_the_separate_entry_points(combo):
                      (A.exp_avg_sq, Bm.exp_avg_sq), (A.grad, Bm.grad), (ra.prio, rb.prio), (ra.tree, rb.tree),
                      (A.grad_norm, Bm.grad_norm)):
             assert torch.equal(x, y)
+        # the split-weight fragments the one-call step writes from inside its optimizer pass == a re-split launch
+        for x, y in ((A.policy._prep, Bm.policy._prep), (A.target._prep, Bm.target._prep), (A._prep_bwd, Bm._prep_bwd)):
+            assert torch.equal(x, y)
     assert A.step_count == Bm.step_count == 3
     # the forward fragments the step left behind are those of the new parameters (leaf evaluation uses them as is)
     p, c, g = torch.rand(7, 25, 1).cuda(), torch.rand(7, 10, 6).cuda(), torch.rand(7, 3, 2).cuda()
