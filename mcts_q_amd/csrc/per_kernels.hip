@@ -57,22 +57,29 @@ __device__ __forceinline__ u64 mctsq_mass(double prio, double alpha, int shift) 
 }
 
 // ------------------------------------------------------------------ wave-wide u64 helpers
-__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl(lo, src, 64); hi = __shfl(hi, src, 64);
+// value of lane `src` (wave-uniform) in every lane: two scalar lane reads, no LDS crossbar trip
+__device__ __forceinline__ u64 readlane_u64(u64 v, int src) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
     return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ u64 shfl_up_u64(u64 v, int d) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    lo = __shfl_up(lo, d, 64); hi = __shfl_up(hi, d, 64);
+// DPP move of both halves; lanes the pattern does not reach (row start, rows masked out) read 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, true);
     return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ u64 wave_incl_scan(u64 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u64 o = shfl_up_u64(v, d);
-        if (lane >= d) v += o;
-    }
+// inclusive prefix sum over the 64 lanes (all active): shifts inside the rows of 16 (row_shr:1,2,4,8), then lane 15 of
+// rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2, 3 (row_bcast:31).  ~40 vector instructions;
+// the shuffle form (12 LDS-crossbar permutes in a dependent chain) cost ~0.5 us per tree level of every draw.
+__device__ __forceinline__ u64 wave_incl_scan(u64 v, int) {
+    v += dpp_u64<0x111, 0xf>(v);
+    v += dpp_u64<0x112, 0xf>(v);
+    v += dpp_u64<0x114, 0xf>(v);
+    v += dpp_u64<0x118, 0xf>(v);
+    v += dpp_u64<0x142, 0xa>(v);
+    v += dpp_u64<0x143, 0xc>(v);
     return v;
 }
 
@@ -91,7 +98,7 @@ __device__ u64 prefix_mass(const u64* tree, const PerTree& T, int64_t n, int lan
     }
     // reduce lanes
     const u64 total = wave_incl_scan(acc, lane);
-    return shfl_u64(total, 63);
+    return readlane_u64(total, 63);
 }
 
 // ------------------------------------------------------------------ sample
@@ -141,6 +148,8 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     __shared__ u64 s_head;
     __shared__ double s_red[SMP_WAVES];
     __shared__ unsigned s_last;
+    __shared__ double s_pr[SMP_WAVES];
+    __shared__ int64_t s_g[SMP_WAVES];
     const PerTree& T = a.T;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int top = T.nlev - 1;
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     u64 v = lane < T.cnt[top] ? a.tree[T.off[top] + lane] : 0;
     const u64 sc_top = wave_incl_scan(v, lane);
     const u64 v_top = v;
-    const u64 M = shfl_u64(sc_top, 63);
+    const u64 M = readlane_u64(sc_top, 63);
     __syncthreads();
     const u64 H = a.head != 0 ? s_head : 0;
 
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
         }
         const unsigned long long ball = __ballot(sc_top > tt);
         const int c = ball ? __ffsll((long long)ball) - 1 : 63;
-        t[k] = tt - shfl_u64(sc_top - v_top, c);
+        t[k] = tt - readlane_u64(sc_top - v_top, c);
         g[k] = c;
     }
     for (int l = top - 1; l >= 0; --l) {
@@ -203,34 +212,49 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
             const u64 sc = wave_incl_scan(vv[k], lane);
             const unsigned long long ball = __ballot(sc > t[k]);
             const int c = ball ? __ffsll((long long)ball) - 1 : 63;
-            t[k] -= shfl_u64(sc - vv[k], c);
+            t[k] -= readlane_u64(sc - vv[k], c);
             g[k] = g[k] * 64 + c;
         }
     }
-    // the sampled records start their trip before the (long, fp64) weight arithmetic of lane 0
-    if (a.ga.states) {
+    // ---- tails.  The draw's priority and its two records start their trips together; the fp64 weight arithmetic
+    // (two software pows: ~500 dependent instructions) of the workgroup's 16 draws runs on 16 lanes of wave 0 while
+    // the records are in flight -- done by lane 0 of every wave it occupied each of the four SIMDs four times over
+    // (4 us of the kernel, measured) -- and the record stores follow it.
+    static_assert(SMP_PER_WAVE == 1, "one draw per wave");
+    const bool lv = live[0];
+    const int64_t gm = g[0] < a.cap ? g[0] : a.cap - 1;      // clamp unreachable for consistent trees
+    double prv = 0.0;
+    if (lane == 0 && lv) prv = a.prio[gm];                    // first in the queue: wave 0 waits for these
+    const bool gath = a.ga.states != nullptr && d0 < a.B;     // wave-uniform
+    const int64_t phys = lv ? gm : 0;
+    float r0[2] = {0.f, 0.f}, r1[2] = {0.f, 0.f}, rrew = 0.f, rdone = 0.f;
+    int32_t ract = 0;
+    if (gath) {
 #pragma unroll
-        for (int k = 0; k < SMP_PER_WAVE; ++k) {
-            const int64_t d = d0 + k;
-            if (d < a.B) gather_record(a.ga, d, live[k] ? (g[k] < a.cap ? g[k] : a.cap - 1) : 0, lane);
+        for (int which = 0; which < 2; ++which) {
+            const float* src = (which ? a.ga.next_states : a.ga.states) + phys * MCTSQ_STATE_ROW;
+            r0[which] = src[lane];
+            r1[which] = lane < 27 ? src[64 + lane] : 0.0f;
         }
+        if (lane == 0) { ract = a.ga.actions[phys]; rrew = a.ga.rewards[phys]; rdone = a.ga.dones[phys]; }
     }
-    // lane k finishes draw k: indices and the raw IS weight (N p_i / sum p)^-beta
-    double wraw = 0.0;
-    {
-        int64_t gm = 0; bool lv = false;
-#pragma unroll
-        for (int k = 0; k < SMP_PER_WAVE; ++k) if (lane == k) { gm = g[k]; lv = live[k]; }
-        if (gm >= a.cap) gm = a.cap - 1;                     // unreachable for consistent trees
-        const int64_t d = d0 + lane;
-        if (lane < SMP_PER_WAVE && d < a.B) {
-            if (lv) {
-                int64_t logical = gm - a.head;
+    if (lane == 0) {
+        s_pr[wv] = prv;
+        s_g[wv] = lv ? gm : -1;
+    }
+    __syncthreads();
+    if (wv == 0 && lane < SMP_DRAWS) {
+        const int64_t d = (int64_t)blockIdx.x * SMP_DRAWS + lane;
+        if (d < a.B) {
+            const int64_t gd = s_g[lane];
+            double wraw = 0.0;
+            if (gd >= 0) {
+                int64_t logical = gd - a.head;
                 if (logical < 0) logical += a.cap;
                 a.idx_out[d] = logical;
-                a.phys_out[d] = gm;
+                a.phys_out[d] = gd;
                 // the mass the sampler used (clamped like mctsq_mass), so weights and sampling law agree
-                const double p = fmin(mctsq_pow_det(a.prio[gm], a.alpha), 256.0);
+                const double p = fmin(mctsq_pow_det(s_pr[lane], a.alpha), 256.0);
                 const double ratio = ((n_eff > 0.0 ? n_eff : (double)a.size) * p) * ldexp(1.0, a.shift) /
                                      (mass_eff > 0.0 ? mass_eff : (double)M);
                 wraw = mctsq_pow_det(ratio, -a.beta);
@@ -241,19 +265,29 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
             __hip_atomic_store(&a.w64[d], wraw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (gath) {
+        const int64_t b = d0;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float* pp = which ? a.ga.nprice : a.ga.sprice; float* pc = which ? a.ga.nprocess : a.ga.sprocess;
+            float* pg = which ? a.ga.ngas : a.ga.sgas;
+            if (lane < 25) pp[b * 25 + lane] = r0[which]; else pc[b * 60 + (lane - 25)] = r0[which];
+            if (lane < 21) pc[b * 60 + 39 + lane] = r1[which]; else if (lane < 27) pg[b * 6 + (lane - 21)] = r1[which];
+        }
+        if (lane == 0) { a.ga.act[b] = ract; a.ga.rew[b] = rrew; a.ga.done[b] = rdone; }
+    }
     if (!a.w && !a.wmax) return;
-    // ---- workgroup maximum of the raw weights, then the ticket -------------------------------------------
-    double mx = wraw;
-    for (int dd = 2; dd >= 1; dd >>= 1) mx = fmax(mx, __shfl_xor(mx, dd, 64));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's sc1 stores have left before it signals
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == gridDim.x - 1 ? 1u : 0u;
+    // ---- the ticket: wave 0 wrote the workgroup's raw weights, so its own wait orders them before its signal ----
+    if (wv == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == gridDim.x - 1 ? 1u : 0u;
+        }
     }
     __syncthreads();
     if (!s_last) return;
-    mx = 0.0;
+    double mx = 0.0;
     for (int64_t i = tid; i < a.B; i += SMP_THREADS)
         mx = fmax(mx, __hip_atomic_load(&a.w64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     for (int dd = 32; dd >= 1; dd >>= 1) mx = fmax(mx, __shfl_xor(mx, dd, 64));
