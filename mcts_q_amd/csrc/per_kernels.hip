@@ -154,6 +154,16 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int top = T.nlev - 1;
     const bool l2_staged = top >= 1 && T.cnt[top - 1] <= SMP_L2MAX;
+    // the draw's uniform / target starts its trip together with the tree's top levels
+    const int64_t d0 = (int64_t)blockIdx.x * SMP_DRAWS + wv * SMP_PER_WAVE;
+    double u_in[SMP_PER_WAVE];
+    u64 t_in[SMP_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < SMP_PER_WAVE; ++k) {
+        const int64_t d = d0 + k;
+        u_in[k] = d < a.B && !a.targets ? a.u[d] : 0.0;
+        t_in[k] = d < a.B && a.targets ? a.targets[d] : 0;
+    }
     if (l2_staged)
         for (int i = tid; i < (int)T.cnt[top - 1]; i += SMP_THREADS) s_l2[i] = a.tree[T.off[top - 1] + i];
     if (a.head != 0 && wv == 0) {                            // logical order starts at `head`
@@ -174,7 +184,6 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     __syncthreads();
     const u64 H = a.head != 0 ? s_head : 0;
 
-    const int64_t d0 = (int64_t)blockIdx.x * SMP_DRAWS + wv * SMP_PER_WAVE;
     u64 t[SMP_PER_WAVE];
     int64_t g[SMP_PER_WAVE];
     bool live[SMP_PER_WAVE];
@@ -185,10 +194,10 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
         u64 tt = 0;
         if (live[k]) {
             if (a.targets) {
-                tt = a.targets[d];                           // sharded: local integer target
+                tt = t_in[k];                                // sharded: local integer target
             } else {
                 // u = k / 2^53 exactly (numpy random_sample); target t = floor(k * M / 2^53)
-                const u64 kk = (u64)(a.u[d] * 9007199254740992.0);
+                const u64 kk = (u64)(u_in[k] * 9007199254740992.0);
                 const u64 hi = __umul64hi(kk, M), lo = kk * M;
                 tt = (hi << 11) | (lo >> 53);
             }
