@@ -911,6 +911,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WJobList jl, const float* __
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const float* __restrict__ partials,
                                                            float* __restrict__ grad, int64_t total, ReduceExtras ex) {
     __shared__ double s_sq[4];
+    // the loss: the per-tile partials folded by one wave in a fixed order (lane l takes parts l, l + 64, ..., then a
+    // shuffle tree).  One thread adding them in turn was a chain of n dependent loads -- the compiler waits for each
+    // before it issues the next --, 64 of them at B = 1024: half of this kernel's time.
+    if (ex.loss_parts && blockIdx.x == 0 && threadIdx.x < 64) {
+        double t = 0.0;
+        for (int i0 = 0; i0 < ex.n_loss_parts; i0 += 256) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u + threadIdx.x;
+                const double x = ex.loss_parts[i < ex.n_loss_parts ? i : 0];
+                v[u] = i < ex.n_loss_parts ? x : 0.0;
+            }
+            t += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (threadIdx.x == 0) *ex.loss_out = (float)(t * ex.loss_norm);
+    }
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float written = 0.0f;
     if (e < total) {
@@ -960,11 +978,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const fl
         if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
         __syncthreads();
         if (threadIdx.x == 0) ex.sumsq_parts[blockIdx.x] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
-    }
-    if (ex.loss_parts && blockIdx.x == 0 && threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < ex.n_loss_parts; ++i) t += ex.loss_parts[i];
-        *ex.loss_out = (float)(t * ex.loss_norm);
     }
 }
 

@@ -67,7 +67,17 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_polyak_kernel(AdamArgs
         }
     } else if (threadIdx.x < 64) {                // every block folds the same 256 partials, same order
         double acc = 0.0;
-        for (int i = threadIdx.x; i < a.npart; i += 64) acc += a.part[i];
+        for (int i0 = 0; i0 < a.npart; i0 += 512) {           // eight loads in flight (a plain loop waits for each in turn)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u + threadIdx.x;
+                const double x = a.part[i < a.npart ? i : 0];
+                v[u] = i < a.npart ? x : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if (threadIdx.x == 0) {
             const float total = (float)sqrt(acc);
