@@ -932,15 +932,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const fl
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float written = 0.0f;
     if (e < total) {
-        int64_t base = 0;
+        // which job: a scan of the compact start table without an early exit, so its scalar loads go out together (a
+        // walk over the job records with a break was ~40 dependent fetches from the kernel-argument block: 8 of this
+        // kernel's 11 us)
         int ji = 0;
-        for (; ji < jl.njobs; ++ji) {
-            const int64_t n = (int64_t)jl.job[ji].M * jl.job[ji].N + jl.job[ji].M;
-            if (e < base + n) break;
-            base += n;
-        }
+#pragma unroll 8
+        for (int k = 1; k < jl.njobs; ++k)
+            if (e >= jl.red_e0[k]) ji = k;
         const WJob& J = jl.job[ji];
-        const int64_t le = e - base, mn = (int64_t)J.M * J.N, stride = mn + J.M;
+        const int le = (int)e - jl.red_e0[ji], mn = J.M * J.N, stride = mn + J.M;
         const float* p = partials + J.part_off + le;
         float acc = 0.0f;
         int sp = 0;
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WJobList jl, const fl
         for (; sp < J.nsplit; ++sp) acc += p[(int64_t)sp * stride];
         if (le < mn) {
             if (J.out_w >= 0) {
-                const int64_t m = le / J.N, n = le - m * J.N;
+                const int m = (int)((unsigned)le / (unsigned)J.N), n = le - m * J.N;
                 grad[J.out_w + m * (int64_t)J.out_ldm + n * (int64_t)J.out_sn] = acc;
                 written = acc;
             }
@@ -998,9 +998,17 @@ int wgrad_reduce_blocks(const WJobList& jl) { return jl.njobs == 0 ? 0 : (int)((
 int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, const ReduceExtras* ex, hipStream_t st) {
     if (jl.njobs == 0) return 0;
     const int64_t total = reduce_total(jl);
+    MCTSQ_CHECK(total < ((int64_t)1 << 31), "too many gradient entries for one reduction launch");
     ReduceExtras e;
     if (ex) e = *ex; else memset(&e, 0, sizeof(e));
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, jl, partials,
+    WJobList l = jl;
+    int64_t pos = 0;
+    for (int i = 0; i < l.njobs; ++i) {
+        l.red_e0[i] = (int32_t)pos;
+        pos += (int64_t)l.job[i].M * l.job[i].N + l.job[i].M;
+    }
+    for (int i = l.njobs; i <= MAX_WJOBS; ++i) l.red_e0[i] = (int32_t)pos;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, l, partials,
                        grad, total, e);
     MCTSQ_HIP(hipGetLastError());
     return 0;

@@ -117,6 +117,9 @@ struct WJob {                   // 80 bytes: a whole network's job list fits one
 struct WJobList {
     WJob job[MAX_WJOBS];
     int njobs, nblocks_total;
+    // first reduced entry of every job (filled by launch_wgrad_reduce): the reduction finds an entry's job from this
+    // compact table (three cache lines of the kernel-argument block) instead of walking the 80-byte job records
+    int32_t red_e0[MAX_WJOBS + 1];
 };
 int launch_wgrad(const WJobList& jl, const float* ws, float* partials, hipStream_t st);
 // sumsq_parts (optional): one fp64 sum of squares of the reduced gradient entries per block of this launch
