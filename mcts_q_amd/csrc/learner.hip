@@ -404,6 +404,13 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
             for (int pl = 0; pl < 3; ++pl) wt[c][pl] = wp[(c * 3 + pl) * 64];
     }
     const float lnw = s.lnw[j], awj = s.aw[j];
+    // The hidden states the pooling backward multiplies by start their trip here, all at once and without a condition
+    // around the loads (index clamped instead): fetched in rounds of eight behind the LayerNorm part, each round was
+    // one more exposed memory round trip (four for the 25-step window) before the first BPTT step could start.
+    constexpr int HB = RPL == 2 ? 32 : 8;                      // RPL 4: eight in flight keep the kernel under 256 registers
+    RowVec<RPL> hv[HB];
+#pragma unroll
+    for (int u = 0; u < HB; ++u) hv[u] = rec(s.sv_h, (u < S ? u : S - 1) + 1);
 
     // ---- LayerNorm backward -> dpool -------------------------------------------------------
     float dpool[RPL], pooled[RPL], mrun[RPL], linv[RPL];
@@ -438,13 +445,13 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
         const float v = row16_sum(dpool[r] * pooled[r]);
         if (jl == 0) L.red[2][wq][4 * q + r] = v;
     }
-    for (int t0 = 0; t0 < S; t0 += 8) {                       // 8 records in flight per lane, then the sums
-        RowVec<RPL> hv[8];
+    for (int t0 = 0; t0 < S; t0 += HB) {
+        if (t0 > 0) {                                          // windows longer than one round (not the shipped ones)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (t0 + u < S) hv[u] = rec(s.sv_h, t0 + u + 1);
+            for (int u = 0; u < HB; ++u) hv[u] = rec(s.sv_h, (t0 + u < S ? t0 + u : S - 1) + 1);
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < HB; ++u) {
             if (t0 + u >= S) break;
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
