@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MCTSQ_ABI_VERSION 3
+#define MCTSQ_ABI_VERSION 4
 
 /* encoder kinds (dqn_per.py:181-203) */
 enum { MCTSQ_ENC_CONV = 1, MCTSQ_ENC_GRU = 2, MCTSQ_ENC_TRANSFORMER = 3, MCTSQ_ENC_MLP = 4 };
@@ -185,6 +185,12 @@ typedef struct {
     const double* d_u; int64_t B;
     float* d_loss; float* d_gnorm; double* d_wmax;
     void* d_ws; int64_t ws_bytes;
+    /* 0: the fragments are re-split at the END of the call (they are current when it returns, as above).
+     * 1: deferred re-split for back-to-back steps: the call re-splits the fragments at its START, on a helper lane
+     *    under the sampling launch (neither depends on the other), and leaves them STALE at its end - pass 1 again
+     *    on the next call, or call mctsq_dqn_prepare / mctsq_q_prepare before using the fragments elsewhere.  Same
+     *    results; the re-split launch and its boundary leave the step's serial chain. */
+    int64_t resplit_first;
 } mctsq_step_args;
 int64_t mctsq_per_dqn_step_workspace_bytes(const mctsq_net_desc* net, int64_t B);
 int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_args* args, void* stream);

@@ -36,7 +36,7 @@ class StepArgs(C.Structure):
                                       "d_prep_target", "d_prep_bwd")]
                 + [(n, _f64) for n in ("gamma", "lr", "beta1", "beta2", "eps", "max_norm", "tau")]
                 + [("adam_step", _i64), ("d_u", _vp), ("B", _i64), ("d_loss", _vp), ("d_gnorm", _vp), ("d_wmax", _vp),
-                   ("d_ws", _vp), ("ws_bytes", _i64)])
+                   ("d_ws", _vp), ("ws_bytes", _i64), ("resplit_first", _i64)])
 
 # name -> (restype, argtypes); every symbol declared in include/mctsq_hip.h
 SIGNATURES = {

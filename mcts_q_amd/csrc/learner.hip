@@ -620,27 +620,10 @@ __global__ __launch_bounds__(256) void gru_prepare_bwd_kernel(GruPrepBwdArgs a) 
     prep_gru_bwd(a.whh[slot], a.out[slot], tid - slot * 1536);
 }
 
-// ---- the learner's one-launch prepare (all-GRU network, 192-128-128-A head): block ranges
-//   [0, 18) policy W_hh forward   [18, 36) target W_hh forward   [36, 54) policy W_hh backward
-//   [54, 75) policy head forward  [75, 96) target head forward   [96, 118) policy head backward
-__global__ __launch_bounds__(256) void dqn_prepare_kernel(DqnPrepArgs a) {
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (b < 36) {
-        const int net = b / 18, tid = (b - net * 18) * 256 + t, slot = tid / 1536;
-        prep_gru_fwd(a.whh[net][slot], a.gru_fwd[net] + (int64_t)slot * (GRU_PREP_BYTES / 16), tid - slot * 1536);
-    } else if (b < 54) {
-        const int tid = (b - 36) * 256 + t, slot = tid / 1536;
-        prep_gru_bwd(a.whh[0][slot], a.gru_bwd[slot], tid - slot * 1536);
-    } else if (b < 96) {
-        const int net = (b - 54) / 21, tid = (b - 54 - net * 21) * 256 + t;
-        prep_head_fwd(a.hw[net][0], a.hw[net][1], a.hw[net][2], a.A, a.head_fwd[net], tid);
-    } else {
-        prep_head_bwd(a.hw[0][0], a.hw[0][1], a.hw[0][2], a.A, a.head_bwd, (b - 96) * 256 + t);
-    }
-}
+// ---- the learner's one-launch prepare (all-GRU network, 192-128-128-A head): prepare_core.hpp: dqn_prepare_block
+__global__ __launch_bounds__(256) void dqn_prepare_kernel(DqnPrepArgs a) { dqn_prepare_block(a, blockIdx.x, threadIdx.x); }
 int launch_dqn_prepare(const DqnPrepArgs& a, hipStream_t st) {
-    static_assert(HEAD_PREP_THREADS == 21 * 256 && HEAD_PREP_BWD_THREADS == 22 * 256, "block ranges of dqn_prepare_kernel");
-    hipLaunchKernelGGL(dqn_prepare_kernel, dim3(118), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(dqn_prepare_kernel, dim3(DQN_PREP_BLOCKS), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

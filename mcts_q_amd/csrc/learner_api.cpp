@@ -258,6 +258,26 @@ int prepare_bwd(const NetLayout& L, const float* params, void* bwd, hipStream_t 
 }
 }  // namespace
 
+namespace {
+bool one_launch_prepare(const NetLayout& L) { return n_gru_slots(L) == 3 && head_is_bf16(L); }
+void fill_dqn_prep(const NetLayout& L, const float* d_params, const float* d_target_params, void* d_prep_policy,
+                   void* d_prep_target, void* d_prep_bwd, DqnPrepArgs* out) {
+    DqnPrepArgs& a = *out;
+    const float* par[2] = {d_params, d_target_params};
+    void* fwd[2] = {d_prep_policy, d_prep_target};
+    for (int n = 0; n < 2; ++n) {
+        for (int s = 0; s < 3; ++s) a.whh[n][s] = par[n] + L.enc[s].gru.whh;
+        for (int l = 0; l < 3; ++l) a.hw[n][l] = par[n] + L.fc_w[l];
+        a.gru_fwd[n] = reinterpret_cast<u32x4*>(fwd[n]);
+        a.head_fwd[n] = reinterpret_cast<u32x4*>((char*)fwd[n] + 3 * GRU_PREP_BYTES);
+    }
+    a.head_bwd = reinterpret_cast<u32x4*>(d_prep_bwd);
+    for (int s = 0; s < 3; ++s)
+        a.gru_bwd[s] = reinterpret_cast<u32x4*>((char*)d_prep_bwd + HEAD_PREP_BWD_BYTES + s * GRU_PREP_BYTES);
+    a.A = L.A;
+}
+}  // namespace
+
 extern "C" int64_t mctsq_dqn_prepared_bwd_bytes(const mctsq_net_desc* net) {
     NetLayout L;
     if (build_layout(net, &L)) return -1;
@@ -274,20 +294,9 @@ extern "C" int mctsq_dqn_prepare(const mctsq_net_desc* net, const float* d_param
     MCTSQ_CHECK((((uintptr_t)d_prep_policy | (uintptr_t)d_prep_target | (uintptr_t)d_prep_bwd) & 15) == 0,
                 "prepared buffers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (n_gru_slots(L) == 3 && head_is_bf16(L)) {           // shipped default: one launch for all of it
+    if (one_launch_prepare(L)) {                             // shipped default: one launch for all of it
         DqnPrepArgs a;
-        const float* par[2] = {d_params, d_target_params};
-        void* fwd[2] = {d_prep_policy, d_prep_target};
-        for (int n = 0; n < 2; ++n) {
-            for (int s = 0; s < 3; ++s) a.whh[n][s] = par[n] + L.enc[s].gru.whh;
-            for (int l = 0; l < 3; ++l) a.hw[n][l] = par[n] + L.fc_w[l];
-            a.gru_fwd[n] = reinterpret_cast<u32x4*>(fwd[n]);
-            a.head_fwd[n] = reinterpret_cast<u32x4*>((char*)fwd[n] + 3 * GRU_PREP_BYTES);
-        }
-        a.head_bwd = reinterpret_cast<u32x4*>(d_prep_bwd);
-        for (int s = 0; s < 3; ++s)
-            a.gru_bwd[s] = reinterpret_cast<u32x4*>((char*)d_prep_bwd + HEAD_PREP_BWD_BYTES + s * GRU_PREP_BYTES);
-        a.A = L.A;
+        fill_dqn_prep(L, d_params, d_target_params, d_prep_policy, d_prep_target, d_prep_bwd, &a);
         return launch_dqn_prepare(a, st);
     }
     if (prepared_bytes(L) > 0) {
@@ -785,11 +794,31 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
     float* np_ = (float*)(ws + S.nprice); float* nc = (float*)(ws + S.nprocess); float* ng = (float*)(ws + S.ngas);
     int32_t* act = (int32_t*)(ws + S.act); float* rew = (float*)(ws + S.rew); float* done = (float*)(ws + S.done);
     double* sumsq = (double*)(ws + S.sumsq);
+    // Deferred re-split (args->resplit_first): the fragments of the parameters as the previous step left them are
+    // re-split by extra workgroups of the sampling launch (neither job needs the other), or, for networks without the
+    // one-launch prepare, by their launches ahead of it.  (On a helper lane under the sampling it cost more than it
+    // hid: the two cross-queue hand-offs took the step from 0.167 to 0.180 ms.)
+    const bool resplit_first = a->resplit_first != 0;
+    DqnPrepArgs pa;
+    const DqnPrepArgs* passenger = nullptr;
+    if (resplit_first) {
+        MCTSQ_CHECK((a->d_prep_policy && a->d_prep_target) || prepared_bytes(L) == 0, "NULL prepared-weights pointer");
+        MCTSQ_CHECK(a->d_prep_bwd || prep_bwd_bytes(L) == 0, "NULL backward prepared-weights pointer");
+        MCTSQ_CHECK((((uintptr_t)a->d_prep_policy | (uintptr_t)a->d_prep_target | (uintptr_t)a->d_prep_bwd) & 15) == 0,
+                    "prepared buffers must be 16-byte aligned");
+        if (one_launch_prepare(L)) {
+            fill_dqn_prep(L, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd, &pa);
+            passenger = &pa;
+        } else if (mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target,
+                                     a->d_prep_bwd, stream)) {
+            return -1;
+        }
+    }
     // sample + IS weights + batch assembly (dqn_per.py:412-452)
-    int rc = mctsq_per_sample_batch(a->d_tree, a->d_prio, a->capacity, a->head, a->size, a->d_u, a->B, a->alpha, a->beta,
-                                    a->mass_capacity, d_idx, d_phys, d_w, a->d_wmax, a->d_states, a->d_next_states,
-                                    a->d_actions, a->d_rewards, a->d_dones, sp, sc, sg, np_, nc, ng, act, rew, done,
-                                    a->d_per_ws, a->per_ws_bytes, stream);
+    int rc = per_sample_batch_impl(a->d_tree, a->d_prio, a->capacity, a->head, a->size, a->d_u, a->B, a->alpha, a->beta,
+                                   a->mass_capacity, d_idx, d_phys, d_w, a->d_wmax, a->d_states, a->d_next_states,
+                                   a->d_actions, a->d_rewards, a->d_dones, sp, sc, sg, np_, nc, ng, act, rew, done,
+                                   a->d_per_ws, a->per_ws_bytes, passenger, stream);
     if (rc) return rc;
     // loss, backward (:455-470); the priority write-back (:474) rides on the helper lane behind the TD errors
     MCTSQ_CHECK(a->d_tree && a->d_prio && a->d_stamp, "NULL device pointer");
@@ -807,8 +836,9 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
                                    a->lr, a->beta1, a->beta2, a->eps, a->max_norm, a->tau, a->d_gnorm, sumsq, nparts,
                                    nullptr, 0, stream);
     if (rc) return rc;
-    rc = mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd,
-                           stream);
+    if (!resplit_first)
+        rc = mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd,
+                               stream);
     // the priority write-back ran on the helper lane next to reduction / optimizer: join it here, so that everything of
     // the step is ordered before whatever the caller enqueues next (by now the event has long fired: waiting for it
     // ahead of the optimizer cost a dependent cross-queue hand-off on the critical path)

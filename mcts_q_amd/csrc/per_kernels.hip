@@ -6,6 +6,7 @@
 // masses - and with them every sampled index - are bit-identical on CPU and GPU.
 #include "device_utils.hpp"
 #include "per.hpp"
+#include "prepare_core.hpp"
 
 #include <string.h>
 
@@ -128,6 +129,9 @@ struct PerSampleArgs {
     int64_t *idx_out, *phys_out; double* w64;
     float* w; double* wmax; unsigned* ticket;     // fused normalisation (w may be NULL)
     PerGatherArgs ga;             // fused gather when ga.states != NULL
+    int nsample;                  // workgroups that sample; the ones behind them re-split weights (prep) when has_prep
+    int has_prep;
+    DqnPrepArgs prep;
 };
 
 __device__ __forceinline__ void gather_record(const PerGatherArgs& a, int64_t b, int64_t phys, int lane) {
@@ -150,6 +154,11 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     __shared__ unsigned s_last;
     __shared__ double s_pr[SMP_WAVES];
     __shared__ int64_t s_g[SMP_WAVES];
+    if ((int)blockIdx.x >= a.nsample) {                      // passenger workgroups: four 256-thread prepare blocks each
+        dqn_prepare_block(a.prep, ((int)blockIdx.x - a.nsample) * (SMP_THREADS / 256) + (int)(threadIdx.x >> 8),
+                          (int)(threadIdx.x & 255));
+        return;
+    }
     const PerTree& T = a.T;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int top = T.nlev - 1;
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == gridDim.x - 1 ? 1u : 0u;
+            s_last = old == (unsigned)a.nsample - 1 ? 1u : 0u;
         }
     }
     __syncthreads();
@@ -644,7 +653,9 @@ static int sample_launch(PerSampleArgs& a, void* ws, hipStream_t st) {
     const bool fused_norm = (a.w || a.wmax) && a.B <= SMP_FUSED_NORM_MAX && ws != nullptr;
     float* w = a.w; double* wmax = a.wmax;
     if (!fused_norm) { a.w = nullptr; a.wmax = nullptr; }
-    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)((a.B + SMP_DRAWS - 1) / SMP_DRAWS)), dim3(SMP_THREADS), 0, st, a);
+    a.nsample = (int)((a.B + SMP_DRAWS - 1) / SMP_DRAWS);
+    const int nprep = a.has_prep ? (DQN_PREP_BLOCKS * 256 + SMP_THREADS - 1) / SMP_THREADS : 0;
+    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)(a.nsample + nprep)), dim3(SMP_THREADS), 0, st, a);
     if (!fused_norm && w) hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, w, wmax);
     else if (!fused_norm && wmax) hipLaunchKernelGGL(per_weight_max_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, wmax);
     MCTSQ_HIP(hipGetLastError());
@@ -653,9 +664,11 @@ static int sample_launch(PerSampleArgs& a, void* ws, hipStream_t st) {
 
 int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                       const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
-                      int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st) {
+                      int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st,
+                      const DqnPrepArgs* prep) {
     PerSampleArgs a;
     memset(&a, 0, sizeof(a));
+    if (prep) { a.has_prep = 1; a.prep = *prep; }
     if (per_tree_desc(cap, &a.T)) return -1;
     a.tree = tree; a.prio = prio; a.cap = cap; a.head = head; a.size = size; a.u = u; a.B = B;
     a.alpha = alpha; a.beta = beta; a.shift = per_mass_shift(mass_cap);

@@ -96,4 +96,26 @@ struct DqnPrepArgs {
 };
 int launch_dqn_prepare(const DqnPrepArgs& a, hipStream_t st);
 
+// ---- the one-launch prepare as a function of (256-thread block b of DQN_PREP_BLOCKS, thread t): block ranges
+//   [0, 18) policy W_hh forward   [18, 36) target W_hh forward   [36, 54) policy W_hh backward
+//   [54, 75) policy head forward  [75, 96) target head forward   [96, 118) policy head backward
+// dqn_prepare_kernel runs it as its grid; the learner step's sampling launch carries it in extra workgroups
+// (per_kernels.hip), so that back-to-back steps pay no launch for it.
+constexpr int DQN_PREP_BLOCKS = 118;
+static_assert(HEAD_PREP_THREADS == 21 * 256 && HEAD_PREP_BWD_THREADS == 22 * 256, "block ranges of dqn_prepare_block");
+__device__ __forceinline__ void dqn_prepare_block(const DqnPrepArgs& a, int b, int t) {
+    if (b < 36) {
+        const int net = b / 18, tid = (b - net * 18) * 256 + t, slot = tid / 1536;
+        prep_gru_fwd(a.whh[net][slot], a.gru_fwd[net] + (int64_t)slot * (GRU_PREP_BYTES / 16), tid - slot * 1536);
+    } else if (b < 54) {
+        const int tid = (b - 36) * 256 + t, slot = tid / 1536;
+        prep_gru_bwd(a.whh[0][slot], a.gru_bwd[slot], tid - slot * 1536);
+    } else if (b < 96) {
+        const int net = (b - 54) / 21, tid = (b - 54 - net * 21) * 256 + t;
+        prep_head_fwd(a.hw[net][0], a.hw[net][1], a.hw[net][2], a.A, a.head_fwd[net], tid);
+    } else if (b < DQN_PREP_BLOCKS) {
+        prep_head_bwd(a.hw[0][0], a.hw[0][1], a.hw[0][2], a.A, a.head_bwd, (b - 96) * 256 + t);
+    }
+}
+
 }  // namespace mctsq

@@ -151,7 +151,10 @@ class DeviceLearner:
             raise ValueError("cannot sample from an empty buffer")
         u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
         B = int(u.numel())
-        self._ensure_prepared()
+        # Deferred re-split: the call re-splits the weight fragments at its START, on a helper lane under the sampling
+        # launch, and leaves them stale at its end (one launch and one boundary less on the step's serial chain).
+        # Whoever needs the fragments next re-splits them itself: the next step(), compute_grad() through
+        # _ensure_prepared(), a leaf evaluation through DeviceQNet._prepared().
         a = getattr(self, "_step_args", None)
         if a is None or self._step_B != B or self._step_replay is not replay:
             need = lib.check(lib.mctsq_per_dqn_step_workspace_bytes(C.byref(self.desc), B))
@@ -178,9 +181,10 @@ class DeviceLearner:
         self.step_count += 1
         a.adam_step = self.step_count
         a.d_u = ptr(u)
+        a.resplit_first = 1
         lib.check(lib.mctsq_per_dqn_step(C.byref(self.desc), C.byref(a), self._st()))
-        self._prep_versions = (self.policy.flat._version, self.target.flat._version)   # the call re-prepared them
-        self.policy._prep_version, self.target._prep_version = self._prep_versions
+        self._prep_versions = None                          # parameters moved behind the fragments
+        self.policy._prep_version = self.target._prep_version = None
         r._max_dirty = True
 
     def update_target(self, tau: float = 1.0):

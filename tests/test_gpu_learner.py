@@ -297,6 +297,7 @@ def test_one_call_step_equals_the_separate_entry_points(combo):
     A, Bm = DeviceLearner(spec).load_state_dict(sd), DeviceLearner(spec).load_state_dict(sd)
     ra, rb = _filled_replay(), _filled_replay()
     rng = np.random.RandomState(8)
+    prev_prep = None
     for it in range(3):
         u = rng.random_sample(100)
         A.step(ra, u, tau=0.005)
@@ -310,11 +311,15 @@ def test_one_call_step_equals_the_separate_entry_points(combo):
                      (A.exp_avg_sq, Bm.exp_avg_sq), (A.grad, Bm.grad), (ra.prio, rb.prio), (ra.tree, rb.tree),
                      (A.grad_norm, Bm.grad_norm)):
             assert torch.equal(x, y)
-        # the split-weight fragments the one-call step writes from inside its optimizer pass == a re-split launch
-        for x, y in ((A.policy._prep, Bm.policy._prep), (A.target._prep, Bm.target._prep), (A._prep_bwd, Bm._prep_bwd)):
-            assert torch.equal(x, y)
+        # deferred re-split: the one-call step re-splits the weight fragments at its START (helper lane, under the
+        # sampling) and leaves them stale: what it holds now are the fragments of the parameters BEFORE this step
+        if prev_prep is not None:
+            for x, y in zip((A.policy._prep, A.target._prep, A._prep_bwd), prev_prep):
+                assert torch.equal(x, y)
+        assert A.policy._prep_version is None               # ... and it says so: the next user re-splits
+        prev_prep = [t.clone() for t in (Bm.policy._prep, Bm.target._prep, Bm._prep_bwd)]
     assert A.step_count == Bm.step_count == 3
-    # the forward fragments the step left behind are those of the new parameters (leaf evaluation uses them as is)
+    # a leaf evaluation behind the step re-splits first (DeviceQNet._prepared) and sees the new parameters
     p, c, g = torch.rand(7, 25, 1).cuda(), torch.rand(7, 10, 6).cuda(), torch.rand(7, 3, 2).cuda()
     q1 = A.policy(p, c, g)["q"].clone()
     A.policy.mark_dirty()
