@@ -439,15 +439,15 @@ int mctsq_per_sample_batch(const uint64_t* d_tree, const double* d_prio, int64_t
                                         d_ws, ws_bytes, nullptr, stream);
 }
 
-// prep != NULL: the launch also re-splits the learner's weight fragments (per.hpp: launch_per_sample)
+// extra != NULL: the launch also carries the learner step's passengers (per.hpp: SamplePassengers)
 extern "C++" int mctsq::per_sample_batch_impl(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
                                  int64_t size, const double* d_u, int64_t B, double alpha, double beta,
                                  int64_t mass_capacity, int64_t* d_idx, int64_t* d_phys, float* d_w, double* d_wmax,
                                  const float* d_states, const float* d_next_states, const int32_t* d_actions,
                                  const float* d_rewards, const float* d_dones, float* d_sprice, float* d_sprocess,
                                  float* d_sgas, float* d_nprice, float* d_nprocess, float* d_ngas, int32_t* d_act,
-                                 float* d_rew, float* d_done, void* d_ws, int64_t ws_bytes, const DqnPrepArgs* prep,
-                                 void* stream) {
+                                 float* d_rew, float* d_done, void* d_ws, int64_t ws_bytes,
+                                 const SamplePassengers* extra, void* stream) {
     if (check_ring(capacity, head, size) || check_mass_cap(capacity, mass_capacity)) return -1;
     MCTSQ_CHECK(size >= 1, "cannot sample from an empty buffer");
     MCTSQ_CHECK(B >= 0, "negative batch");
@@ -458,7 +458,7 @@ extern "C++" int mctsq::per_sample_batch_impl(const uint64_t* d_tree, const doub
     if (fill_gather(ga, d_states, d_next_states, d_actions, d_rewards, d_dones, d_phys, B, d_sprice, d_sprocess, d_sgas,
                     d_nprice, d_nprocess, d_ngas, d_act, d_rew, d_done)) return -1;
     return launch_per_sample((const unsigned long long*)d_tree, d_prio, capacity, head, size, d_u, B, alpha,
-                             beta, mass_capacity, d_idx, d_phys, d_w, d_wmax, d_ws, &ga, (hipStream_t)stream, prep);
+                             beta, mass_capacity, d_idx, d_phys, d_w, d_wmax, d_ws, &ga, (hipStream_t)stream, extra);
 }
 
 int mctsq_per_shard_select(const double* d_u, int64_t B, const uint64_t* d_shard_mass, int world, int rank,

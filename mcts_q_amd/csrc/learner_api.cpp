@@ -241,6 +241,7 @@ struct DqnPrep { const void* policy; const void* target; const void* bwd; };
 struct PerUpdateHook {
     unsigned long long* tree; double* prio; int32_t* stamp; int64_t cap, head, size; const int64_t* idx;
     double alpha; int64_t mass_cap;
+    bool grad_zeroed;          // the caller's sampling launch zeroed d_grad (passenger): no fill, no fork for it
 };
 
 int prepare_bwd(const NetLayout& L, const float* params, void* bwd, hipStream_t st) {
@@ -351,8 +352,13 @@ static int dqn_grad_entry(const mctsq_net_desc* net, const DqnPrep* pp, const fl
     hipStream_t st = (hipStream_t)stream;
     SideStream side;
     if (side_stream(st, &side)) return -1;
-    MCTSQ_HIP(hipEventRecord(side.fork, st));
-    MCTSQ_HIP(hipStreamWaitEvent(side.st, side.fork, 0));
+    // the helper lane starts with the gradient fill and, without prepared fragments, the backward splits: forked here.
+    // With both done elsewhere its first job waits for the head backward anyway (event `head`): no fork
+    const bool need_fork = !(upd && upd->grad_zeroed && pp);
+    if (need_fork) {
+        MCTSQ_HIP(hipEventRecord(side.fork, st));
+        MCTSQ_HIP(hipStreamWaitEvent(side.st, side.fork, 0));
+    }
     const int rc = dqn_grad_enqueue(L, P, &side, pp, d_params, d_target_params, d_sprice, d_sprocess, d_sgas, d_nprice,
                                     d_nprocess, d_ngas, d_act, d_rew, d_done, d_isw, gamma, loss_scale, B, d_grad,
                                     d_loss, d_abs_td, d_qsa, d_target, d_sumsq_parts, upd, (float*)d_ws, st);
@@ -432,7 +438,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     {
         // the flat gradient's alignment pads must read zero; nothing touches it before the ordered reduction (step 7,
         // behind the join), so the fill rides on the helper stream instead of the critical path
-        MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
+        if (!(upd && upd->grad_zeroed)) MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
         if (!pp) {                                           // ... and so do the splits the backward pass multiplies by
             if (head_bf16 &&
                 launch_head_prepare_bwd(d_params + L.fc_w[0], d_params + L.fc_w[1], d_params + L.fc_w[2], L.A,
@@ -493,6 +499,10 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
                                          d_target_params, pp ? pp->target : nullptr, xn, ws + P.feats_t, out_t, B, Bp, st);
         if (pr < 0) return -1;
         if (pr == 1) {
+            if (upd && upd->grad_zeroed && pp) {              // the caller skipped the fork (dqn_grad_entry): do it now
+                MCTSQ_HIP(hipEventRecord(side->fork, st));
+                MCTSQ_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+            }
             if (target_forward_on_helper()) return -1;
             if (forward_impl(L, d_params, pp ? pp->policy : nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr))
                 return -1;
@@ -800,7 +810,7 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
     // hid: the two cross-queue hand-offs took the step from 0.167 to 0.180 ms.)
     const bool resplit_first = a->resplit_first != 0;
     DqnPrepArgs pa;
-    const DqnPrepArgs* passenger = nullptr;
+    SamplePassengers extra{nullptr, a->d_grad, L.total};     // the gradient fill always rides along
     if (resplit_first) {
         MCTSQ_CHECK((a->d_prep_policy && a->d_prep_target) || prepared_bytes(L) == 0, "NULL prepared-weights pointer");
         MCTSQ_CHECK(a->d_prep_bwd || prep_bwd_bytes(L) == 0, "NULL backward prepared-weights pointer");
@@ -808,7 +818,7 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
                     "prepared buffers must be 16-byte aligned");
         if (one_launch_prepare(L)) {
             fill_dqn_prep(L, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd, &pa);
-            passenger = &pa;
+            extra.prep = &pa;
         } else if (mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target,
                                      a->d_prep_bwd, stream)) {
             return -1;
@@ -818,13 +828,13 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
     int rc = per_sample_batch_impl(a->d_tree, a->d_prio, a->capacity, a->head, a->size, a->d_u, a->B, a->alpha, a->beta,
                                    a->mass_capacity, d_idx, d_phys, d_w, a->d_wmax, a->d_states, a->d_next_states,
                                    a->d_actions, a->d_rewards, a->d_dones, sp, sc, sg, np_, nc, ng, act, rew, done,
-                                   a->d_per_ws, a->per_ws_bytes, passenger, stream);
+                                   a->d_per_ws, a->per_ws_bytes, &extra, stream);
     if (rc) return rc;
     // loss, backward (:455-470); the priority write-back (:474) rides on the helper lane behind the TD errors
     MCTSQ_CHECK(a->d_tree && a->d_prio && a->d_stamp, "NULL device pointer");
     MCTSQ_CHECK(a->B < ((int64_t)1 << 31), "update batch too large");
     PerUpdateHook upd{(unsigned long long*)a->d_tree, a->d_prio, a->d_stamp, a->capacity, a->head, a->size, d_idx,
-                      a->alpha, a->mass_capacity};
+                      a->alpha, a->mass_capacity, true};
     DqnPrep pp{a->d_prep_policy, a->d_prep_target, a->d_prep_bwd};
     rc = dqn_grad_entry(net, &pp, a->d_params, a->d_target_params, sp, sc, sg, np_, nc, ng, act, rew, done, d_w,
                         (float)a->gamma, 1.0f, a->B, a->d_grad, a->d_loss, d_abs_td, nullptr, nullptr, sumsq,

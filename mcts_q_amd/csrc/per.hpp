@@ -29,15 +29,21 @@ struct PerGatherArgs {
 typedef unsigned long long per_u64;
 // sample workspace: control words first (the normalisation ticket), raw fp64 weights behind them
 constexpr int64_t PER_WS_CTRL_BYTES = 64;
-// ga != NULL: the sampled records are gathered by the same launch (ga->phys is ignored).  prep != NULL: extra
-// workgroups of the same launch re-split the learner's weight fragments (prepare_core.hpp: dqn_prepare_block) --
-// the start of a learner step samples from the replay ring and re-splits the weights the previous step left, two
-// jobs that need nothing from each other.
+// ga != NULL: the sampled records are gathered by the same launch (ga->phys is ignored).
+// Passengers (learner step only): extra workgroups of the same launch that do small jobs the start of a step needs and
+// that depend on nothing the sampling does -- re-splitting the weight fragments the previous step left
+// (prepare_core.hpp: dqn_prepare_block) and zeroing the flat gradient buffer.  Each would otherwise be a launch (and
+// ~5 us of host time per runtime call) of its own.
 struct DqnPrepArgs;
+struct SamplePassengers {
+    const DqnPrepArgs* prep;    // or NULL
+    float* zero;                // or NULL: zero_floats floats (a multiple of 4, 16-byte aligned) are set to 0
+    int64_t zero_floats;
+};
 int launch_per_sample(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                       const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
                       int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st,
-                      const DqnPrepArgs* prep = nullptr);
+                      const SamplePassengers* extra = nullptr);
 // mctsq_per_sample_batch with the optional passenger (capi.cpp)
 int per_sample_batch_impl(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head, int64_t size,
                           const double* d_u, int64_t B, double alpha, double beta, int64_t mass_capacity, int64_t* d_idx,
@@ -45,7 +51,7 @@ int per_sample_batch_impl(const uint64_t* d_tree, const double* d_prio, int64_t 
                           const int32_t* d_actions, const float* d_rewards, const float* d_dones, float* d_sprice,
                           float* d_sprocess, float* d_sgas, float* d_nprice, float* d_nprocess, float* d_ngas,
                           int32_t* d_act, float* d_rew, float* d_done, void* d_ws, int64_t ws_bytes,
-                          const DqnPrepArgs* prep, void* stream);
+                          const SamplePassengers* extra, void* stream);
 int launch_per_sample_at(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                          const per_u64* targets, int64_t B, double alpha, double beta, int64_t mass_cap,
                          double n_total, double mass_total, int64_t* idx, int64_t* phys, double* w64, double* wmax,

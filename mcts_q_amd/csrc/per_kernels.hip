@@ -129,9 +129,10 @@ struct PerSampleArgs {
     int64_t *idx_out, *phys_out; double* w64;
     float* w; double* wmax; unsigned* ticket;     // fused normalisation (w may be NULL)
     PerGatherArgs ga;             // fused gather when ga.states != NULL
-    int nsample;                  // workgroups that sample; the ones behind them re-split weights (prep) when has_prep
-    int has_prep;
+    int nsample;                  // workgroups that sample; behind them the passengers (per.hpp): nprep workgroups
+    int nprep;                    // re-split weights (prep), the rest zero `zero`
     DqnPrepArgs prep;
+    float* zero; int64_t zero_n4;
 };
 
 __device__ __forceinline__ void gather_record(const PerGatherArgs& a, int64_t b, int64_t phys, int lane) {
@@ -154,9 +155,14 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     __shared__ unsigned s_last;
     __shared__ double s_pr[SMP_WAVES];
     __shared__ int64_t s_g[SMP_WAVES];
-    if ((int)blockIdx.x >= a.nsample) {                      // passenger workgroups: four 256-thread prepare blocks each
-        dqn_prepare_block(a.prep, ((int)blockIdx.x - a.nsample) * (SMP_THREADS / 256) + (int)(threadIdx.x >> 8),
-                          (int)(threadIdx.x & 255));
+    if ((int)blockIdx.x >= a.nsample) {                      // passenger workgroups
+        const int pb = (int)blockIdx.x - a.nsample;
+        if (pb < a.nprep) {                                  // four 256-thread prepare blocks each
+            dqn_prepare_block(a.prep, pb * (SMP_THREADS / 256) + (int)(threadIdx.x >> 8), (int)(threadIdx.x & 255));
+        } else {
+            const int64_t i = (int64_t)(pb - a.nprep) * SMP_THREADS + threadIdx.x;
+            if (i < a.zero_n4) reinterpret_cast<float4*>(a.zero)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         return;
     }
     const PerTree& T = a.T;
@@ -654,8 +660,8 @@ static int sample_launch(PerSampleArgs& a, void* ws, hipStream_t st) {
     float* w = a.w; double* wmax = a.wmax;
     if (!fused_norm) { a.w = nullptr; a.wmax = nullptr; }
     a.nsample = (int)((a.B + SMP_DRAWS - 1) / SMP_DRAWS);
-    const int nprep = a.has_prep ? (DQN_PREP_BLOCKS * 256 + SMP_THREADS - 1) / SMP_THREADS : 0;
-    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)(a.nsample + nprep)), dim3(SMP_THREADS), 0, st, a);
+    const int nzero = (int)((a.zero_n4 + SMP_THREADS - 1) / SMP_THREADS);
+    hipLaunchKernelGGL(per_sample_kernel, dim3((unsigned)(a.nsample + a.nprep + nzero)), dim3(SMP_THREADS), 0, st, a);
     if (!fused_norm && w) hipLaunchKernelGGL(per_weight_norm_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, w, wmax);
     else if (!fused_norm && wmax) hipLaunchKernelGGL(per_weight_max_kernel, dim3(1), dim3(1024), 0, st, a.w64, a.B, wmax);
     MCTSQ_HIP(hipGetLastError());
@@ -665,10 +671,15 @@ static int sample_launch(PerSampleArgs& a, void* ws, hipStream_t st) {
 int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                       const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
                       int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st,
-                      const DqnPrepArgs* prep) {
+                      const SamplePassengers* extra) {
     PerSampleArgs a;
     memset(&a, 0, sizeof(a));
-    if (prep) { a.has_prep = 1; a.prep = *prep; }
+    if (extra && extra->prep) { a.nprep = (DQN_PREP_BLOCKS * 256 + SMP_THREADS - 1) / SMP_THREADS; a.prep = *extra->prep; }
+    if (extra && extra->zero) {
+        MCTSQ_CHECK(extra->zero_floats % 4 == 0 && ((uintptr_t)extra->zero & 15) == 0 && extra->zero_floats >= 0 &&
+                        extra->zero_floats < ((int64_t)1 << 31), "passenger zero-fill: bad buffer");
+        a.zero = extra->zero; a.zero_n4 = extra->zero_floats / 4;
+    }
     if (per_tree_desc(cap, &a.T)) return -1;
     a.tree = tree; a.prio = prio; a.cap = cap; a.head = head; a.size = size; a.u = u; a.B = B;
     a.alpha = alpha; a.beta = beta; a.shift = per_mass_shift(mass_cap);
