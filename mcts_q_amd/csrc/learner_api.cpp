@@ -199,7 +199,7 @@ namespace {
 // stream are ordered by the caller (one host thread enqueues on a stream at a time).
 struct SideStream {
     hipStream_t st = nullptr, st2 = nullptr;               // helper lanes: encoder backward of the short windows; head products
-    hipEvent_t fork = nullptr, join = nullptr, head = nullptr, join2 = nullptr, join3 = nullptr, upd = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, head = nullptr, join2 = nullptr, join3 = nullptr;
 };
 std::mutex g_side_mu;
 std::map<std::pair<int, void*>, SideStream> g_side;
@@ -216,7 +216,6 @@ int side_stream(hipStream_t caller, SideStream* out) {
         MCTSQ_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.head, hipEventDisableTiming));
         MCTSQ_HIP(hipEventCreateWithFlags(&s.join2, hipEventDisableTiming));
-        MCTSQ_HIP(hipEventCreateWithFlags(&s.upd, hipEventDisableTiming));
     }
     *out = s;
     return 0;
@@ -368,8 +367,7 @@ static int dqn_grad_entry(const mctsq_net_desc* net, const DqnPrep* pp, const fl
         (void)hipEventRecord(side.join3, side.st2);
         (void)hipStreamWaitEvent(st, side.join3, 0);
     }
-    // success: the helper lane was joined before the reduction; only the priority write-back (upd) may still be running
-    // there - its caller (mctsq_per_dqn_step) joins it at the end of the step, behind the optimizer
+    // success: both helper lanes (the priority write-back included) were joined before the reduction
     return rc;
 }
 
@@ -693,15 +691,16 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     // LayerNorm-bias sums (15 us of latency-bound split-K launches), then the priority write-back.  On the first helper
     // lane they sat behind the short windows' backward and made that lane the longest of the three.
     MCTSQ_HIP(hipStreamWaitEvent(side->st2, side->head, 0));
-    for (int i = 0; i < jbA.nlists; ++i)
-        if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st2)) return -1;
-    MCTSQ_HIP(hipEventRecord(side->join3, side->st2));
-    if (upd) {                                                // joined by mctsq_per_dqn_step behind the optimizer
+    if (upd) {                                                // first on the lane: ONE event then covers both jobs (every
+        // runtime call is ~6 us of host time, and the step is close to host-bound); the lane still ends ~20 us before
+        // the caller's stream reaches the reduction
         if (launch_per_update(upd->tree, upd->prio, upd->stamp, upd->cap, upd->head, upd->size, upd->idx, d_abs_td, B,
                               upd->alpha, upd->mass_cap, side->st2))
             return -1;
-        MCTSQ_HIP(hipEventRecord(side->upd, side->st2));
     }
+    for (int i = 0; i < jbA.nlists; ++i)
+        if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st2)) return -1;
+    MCTSQ_HIP(hipEventRecord(side->join3, side->st2));
     // first helper lane: the short windows' weight gradients (their backward is already queued there)
     if (launch_gru_wgrad(gwSide, side->st)) return -1;
     MCTSQ_HIP(hipEventRecord(side->join2, side->st));
@@ -849,12 +848,7 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
     if (!resplit_first)
         rc = mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd,
                                stream);
-    // the priority write-back ran on the helper lane next to reduction / optimizer: join it here, so that everything of
-    // the step is ordered before whatever the caller enqueues next (by now the event has long fired: waiting for it
-    // ahead of the optimizer cost a dependent cross-queue hand-off on the critical path)
-    SideStream side;
-    if (side_stream((hipStream_t)stream, &side)) return -1;
-    MCTSQ_HIP(hipStreamWaitEvent((hipStream_t)stream, side.upd, 0));
+    // (the priority write-back ran first on the second helper lane, which the reduction joined)
     if (rc) return rc;
     return 0;
 }
