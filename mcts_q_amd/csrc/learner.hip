@@ -362,11 +362,10 @@ __device__ __forceinline__ void store_rows(float* p, const RowVec<RPL>& x) {
 }
 
 template <int RPL>
-__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
-    __shared__ __attribute__((aligned(16))) GruBwdLds L;
+__device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& args, int bid) {
     constexpr int NH = 4 / RPL;                                // workgroups per 16-sample tile
-    const int slot = blockIdx.x % args.nslots;
-    const int hb = blockIdx.x / args.nslots;
+    const int slot = bid % args.nslots;
+    const int hb = bid / args.nslots;
     const int64_t tile = hb / NH;
     const int half = hb % NH;
     const int64_t row0 = tile * TILE;
@@ -613,6 +612,22 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     if (wq == 0 && lane == 0) pa[64] = dab;
 }
 
+template <int RPL>
+__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
+    __shared__ __attribute__((aligned(16))) GruBwdLds L;
+    gru_bwd_body<RPL>(L, args, (int)blockIdx.x);
+}
+// Two groups of windows with their own tile modes in ONE launch (workgroups [0, na) the first): the learner's long
+// window on 8-sample tiles next to the short ones on 16-sample tiles.  As two launches on two streams they ran side
+// by side as well, but cost the step a second launch and three event operations (~6 us of host time each; the step is
+// close to host-bound) and a cross-queue hand-off before the reduction.
+template <int RA, int RB>
+__global__ __launch_bounds__(256) void gru_bwd_pair_kernel(GruBwdArgs a, GruBwdArgs b, int na) {
+    __shared__ __attribute__((aligned(16))) GruBwdLds L;
+    if ((int)blockIdx.x < na) gru_bwd_body<RA>(L, a, (int)blockIdx.x);
+    else gru_bwd_body<RB>(L, b, (int)blockIdx.x - na);
+}
+
 struct GruPrepBwdArgs { const float* whh[3]; u32x4* out[3]; };
 __global__ __launch_bounds__(256) void gru_prepare_bwd_kernel(GruPrepBwdArgs a) {
     const int tid = blockIdx.x * 256 + threadIdx.x;           // grid = n * 6 blocks of 256
@@ -645,6 +660,30 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
         MCTSQ_CHECK(a.slot[i].wprep_t && ((uintptr_t)a.slot[i].wprep_t & 15) == 0, "GRU backward needs the transposed prepared weights");
     if (a.half) hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3((unsigned)(a.Bp / TILE * 2 * a.nslots)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gru_bwd_kernel<4>, dim3((unsigned)(a.Bp / TILE * a.nslots)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+int64_t gru_bwd_blocks(const GruBwdArgs& a) { return a.Bp / TILE * (a.half ? 2 : 1) * a.nslots; }
+
+int launch_gru_bwd_pair(const GruBwdArgs& a, const GruBwdArgs& b, hipStream_t st) {
+    if (a.nslots == 0) return launch_gru_bwd(b, st);
+    if (b.nslots == 0) return launch_gru_bwd(a, st);
+    const GruBwdArgs* both[2] = {&a, &b};
+    for (const GruBwdArgs* g : both) {
+        MCTSQ_CHECK(g->Bp % TILE == 0, "padded batch must be a multiple of %d", TILE);
+        for (int i = 0; i < g->nslots; ++i) {
+            MCTSQ_CHECK(g->slot[i].S <= MAX_SEQ, "window too long");
+            MCTSQ_CHECK(g->slot[i].wprep_t && ((uintptr_t)g->slot[i].wprep_t & 15) == 0,
+                        "GRU backward needs the transposed prepared weights");
+        }
+    }
+    const int na = (int)gru_bwd_blocks(a), nb = (int)gru_bwd_blocks(b);
+    const dim3 grid((unsigned)(na + nb));
+    if (a.half && b.half) hipLaunchKernelGGL((gru_bwd_pair_kernel<2, 2>), grid, dim3(256), 0, st, a, b, na);
+    else if (a.half) hipLaunchKernelGGL((gru_bwd_pair_kernel<2, 4>), grid, dim3(256), 0, st, a, b, na);
+    else if (b.half) hipLaunchKernelGGL((gru_bwd_pair_kernel<4, 2>), grid, dim3(256), 0, st, a, b, na);
+    else hipLaunchKernelGGL((gru_bwd_pair_kernel<4, 4>), grid, dim3(256), 0, st, a, b, na);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

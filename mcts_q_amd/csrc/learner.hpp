@@ -58,6 +58,9 @@ struct GruBwdArgs {
 // lane (jl, q) of wave w holds W_hh[32c + 8q .. +7][16w + jl]; GRU_PREP_BYTES per slot
 int launch_gru_prepare_bwd(const float* const whh[3], int n, void* const out[3], hipStream_t st);
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
+int64_t gru_bwd_blocks(const GruBwdArgs& a);
+// both groups of windows in one launch (each with its own tile mode); either may be empty
+int launch_gru_bwd_pair(const GruBwdArgs& a, const GruBwdArgs& b, hipStream_t st);
 
 // ---- GRU weight gradients, all of one slot's big contractions in one pass over the saved tensors ----
 // dW_ih = [dr|dz|dn]^T X, dW_hh[0:128] = [dr|dz]^T H_prev, dW_hh[128:192] = (dn*r)^T H_prev and the

@@ -432,12 +432,17 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             if (L.enc[s].kind == MCTSQ_ENC_GRU) gru_bwd_prep[s] = ws + P.slot[s].wt;
     }
 
+    bool side_used = false;                                  // anything on the first helper lane: joined before the reduction
     // 1. target network on s' -> max_a' Q (dqn_per.py:460-463), on the helper stream (forked by the caller)
     {
         // the flat gradient's alignment pads must read zero; nothing touches it before the ordered reduction (step 7,
         // behind the join), so the fill rides on the helper stream instead of the critical path
-        if (!(upd && upd->grad_zeroed)) MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
+        if (!(upd && upd->grad_zeroed)) {
+            MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
+            side_used = true;
+        }
         if (!pp) {                                           // ... and so do the splits the backward pass multiplies by
+            side_used = true;
             if (head_bf16 &&
                 launch_head_prepare_bwd(d_params + L.fc_w[0], d_params + L.fc_w[1], d_params + L.fc_w[2], L.A,
                                         ws + P.head_prep_bwd, side->st))
@@ -501,6 +506,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
                 MCTSQ_HIP(hipEventRecord(side->fork, st));
                 MCTSQ_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
             }
+            side_used = true;
             if (target_forward_on_helper()) return -1;
             if (forward_impl(L, d_params, pp ? pp->policy : nullptr, xs, B, Bp, ws + P.feats_p, out, sv, sv_act, st, nullptr))
                 return -1;
@@ -529,7 +535,6 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         if (launch_head_bwd(h, st)) return -1;
     }
     MCTSQ_HIP(hipEventRecord(side->head, st));
-    MCTSQ_HIP(hipStreamWaitEvent(side->st, side->head, 0));
 
     // 5./6. encoder backward (deltas) and weight gradients (every tensor is one or a few K-contractions), on two
     // lanes: `jbA` holds the products that need only the head's deltas, `jbB` those behind the encoder backward
@@ -538,6 +543,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     memset(&gwMain, 0, sizeof(gwMain));
     memset(&gwSide, 0, sizeof(gwSide));
     int gru_half[2] = {0, 0};                                 // tile mode of the GRU backward per lane (caller's, helper)
+    bool merged = false;                                      // both groups of GRU windows in ONE launch on the caller's stream
     // the longest GRU window stays on the caller's stream, the others go to the helper stream
     int long_slot = -1;
     for (int s = 0; s < 3; ++s)
@@ -571,8 +577,20 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             else if (nt * (2 * gbMain.nslots + gbSide.nslots) <= 256) gbMain.half = 1;
             gru_half[0] = gbMain.half; gru_half[1] = gbSide.half;
         }
-        if (launch_gru_bwd(gbSide, side->st)) return -1;
-        if (launch_gru_bwd(gbMain, st)) return -1;
+        // One wave of workgroups for both groups together: ONE launch on the caller's stream (and one for their weight
+        // gradients below): the groups run side by side either way, and the first helper lane with its launches, its
+        // three event operations and its hand-off before the reduction is not needed.  Otherwise: two lanes.
+        merged = gbMain.nslots > 0 && gbSide.nslots > 0 && gru_bwd_blocks(gbMain) + gru_bwd_blocks(gbSide) <= 256;
+        if (merged) {
+            if (launch_gru_bwd_pair(gbMain, gbSide, st)) return -1;
+        } else {
+            if (gbSide.nslots > 0) {
+                MCTSQ_HIP(hipStreamWaitEvent(side->st, side->head, 0));
+                if (launch_gru_bwd(gbSide, side->st)) return -1;
+                side_used = true;
+            }
+            if (launch_gru_bwd(gbMain, st)) return -1;
+        }
         MlpArgs ma;
         if (fill_mlp_args(ma, L, d_params, xs, B, Bp, ws + P.feats_p, sv)) {
             ma.dfeat = ws + P.dfeat;
@@ -621,7 +639,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1} -- one fused pass (gru_wgrad_kernel),
             // reduced here in block order
             {
-                GruWgradArgs& gw = s == long_slot ? gwMain : gwSide;
+                GruWgradArgs& gw = (s == long_slot || merged) ? gwMain : gwSide;
                 GruWgradSlot& w = gw.slot[gw.nslots++];
                 w.G = G; w.Hprev = Hprev; w.X = ws + g.x; w.K = (int)K; w.F = e.F; w.rows = g.gw_rows;
                 w.nsplit = g.gw_nsplit; w.blk0 = gw.nblocks;
@@ -701,14 +719,18 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     for (int i = 0; i < jbA.nlists; ++i)
         if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st2)) return -1;
     MCTSQ_HIP(hipEventRecord(side->join3, side->st2));
-    // first helper lane: the short windows' weight gradients (their backward is already queued there)
-    if (launch_gru_wgrad(gwSide, side->st)) return -1;
-    MCTSQ_HIP(hipEventRecord(side->join2, side->st));
-    // caller's stream: the long window's weight gradients and everything else behind the encoder backward
+    // first helper lane: the short windows' weight gradients (their backward is already queued there), unless both
+    // groups went to the caller's stream together
+    if (gwSide.nslots > 0) {
+        if (launch_gru_wgrad(gwSide, side->st)) return -1;
+        side_used = true;
+    }
+    if (side_used) MCTSQ_HIP(hipEventRecord(side->join2, side->st));
+    // caller's stream: the long window's (or all windows') weight gradients and everything else behind the encoder backward
     if (launch_gru_wgrad(gwMain, st)) return -1;
     for (int i = 0; i < jbB.nlists; ++i)
         if (launch_wgrad(jbB.lists[i], ws, ws + P.partials, st)) return -1;
-    MCTSQ_HIP(hipStreamWaitEvent(st, side->join2, 0));
+    if (side_used) MCTSQ_HIP(hipStreamWaitEvent(st, side->join2, 0));
     MCTSQ_HIP(hipStreamWaitEvent(st, side->join3, 0));
     // 7. ordered reduction of all partials into the flat gradient (+ the pieces of its norm, + the loss): the two
     // lanes' job lists are reduced by the same launches (40 jobs each)
