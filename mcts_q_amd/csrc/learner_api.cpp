@@ -709,15 +709,15 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     // LayerNorm-bias sums (15 us of latency-bound split-K launches), then the priority write-back.  On the first helper
     // lane they sat behind the short windows' backward and made that lane the longest of the three.
     MCTSQ_HIP(hipStreamWaitEvent(side->st2, side->head, 0));
-    if (upd) {                                                // first on the lane: ONE event then covers both jobs (every
-        // runtime call is ~6 us of host time, and the step is close to host-bound); the lane still ends ~20 us before
-        // the caller's stream reaches the reduction
+    for (int i = 0; i < jbA.nlists; ++i)
+        if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st2)) return -1;
+    if (upd) {                                                // ONE event covers both jobs of the lane (every runtime call
+        // is ~6-8 us of host time); the write-back is a single workgroup, so behind the products it is the only thing
+        // of this lane that still runs when the weight-gradient launch of the caller's stream needs the CUs
         if (launch_per_update(upd->tree, upd->prio, upd->stamp, upd->cap, upd->head, upd->size, upd->idx, d_abs_td, B,
                               upd->alpha, upd->mass_cap, side->st2))
             return -1;
     }
-    for (int i = 0; i < jbA.nlists; ++i)
-        if (launch_wgrad(jbA.lists[i], ws, ws + P.partials, side->st2)) return -1;
     MCTSQ_HIP(hipEventRecord(side->join3, side->st2));
     // first helper lane: the short windows' weight gradients (their backward is already queued there), unless both
     // groups went to the caller's stream together
