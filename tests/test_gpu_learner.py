@@ -283,11 +283,14 @@ def _filled_replay(n=3000, cap=4096, seed=2):
     return buf
 
 
-@pytest.mark.parametrize("combo", [("gru", "gru", "gru"), ("conv", "gru", "mlp")])
-def test_one_call_step_equals_the_separate_entry_points(combo):
+@pytest.mark.parametrize("combo,B", [(("gru", "gru", "gru"), 100), (("conv", "gru", "mlp"), 100),
+                                     (("gru", "gru", "gru"), 1024), (("gru", "gru", "gru"), 2048)])
+def test_one_call_step_equals_the_separate_entry_points(combo, B):
     """mctsq_per_dqn_step (DQNModel.update as one library call) against sample_batch -> dqn_grad_prepared ->
     clip_adam_polyak_ex -> prepare -> per_update called one by one: parameters, Adam moments, target, priorities
-    and loss bit for bit over three steps (ragged batch: 100 is not a multiple of the 16-row tile)."""
+    and loss bit for bit over three steps.  B = 100: ragged batch (not a multiple of the 16-row tile), every GRU
+    window on 8-sample tiles in one launch; 1024: the long window on 8-sample tiles next to the short ones on
+    16-sample tiles in one launch; 2048: the windows no longer fit one wave of workgroups - two lanes."""
     from mcts_q_amd import NetSpec
     from mcts_q_amd.learner import DeviceLearner
     cfg = dict(price=combo[0], process=combo[1], gas=combo[2], act="relu", flavor="per")
@@ -299,7 +302,7 @@ def test_one_call_step_equals_the_separate_entry_points(combo):
     rng = np.random.RandomState(8)
     prev_prep = None
     for it in range(3):
-        u = rng.random_sample(100)
+        u = rng.random_sample(B)
         A.step(ra, u, tau=0.005)
         batch, w, idx, _ = rb.sample_batch(u)
         abs_td = Bm.compute_grad(batch, w)
