@@ -10,6 +10,7 @@ def _rt():
     if _hip is None:
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        _hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
         _hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
         _hip.hipEventSynchronize.argtypes = [C.c_void_p]
         _hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
@@ -17,10 +18,18 @@ def _rt():
     return _hip
 
 
+HIP_EVENT_DISABLE_TIMING = 0x2
+
+
 class HipEvent:
-    def __init__(self):
+    """timing=False: an ordering-only event (hipEventDisableTiming), cheaper to record and to wait for; the search
+    loop records one per leaf batch."""
+
+    def __init__(self, timing: bool = True):
         self.h = C.c_void_p()
-        if _rt().hipEventCreate(C.byref(self.h)) != 0:
+        rc = (_rt().hipEventCreate(C.byref(self.h)) if timing
+              else _rt().hipEventCreateWithFlags(C.byref(self.h), HIP_EVENT_DISABLE_TIMING))
+        if rc != 0:
             raise RuntimeError("hipEventCreate failed")
 
     def record(self, stream_ptr):

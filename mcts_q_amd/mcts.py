@@ -132,7 +132,8 @@ class DeviceLeafEvaluator:
         from .treesearch import LeafEval
         C = self._C
         if not hasattr(self, "_hipev"):
-            self._hipev = [HipEvent() for _ in range(self.halves)]
+            import os
+            self._hipev = [HipEvent(timing=bool(os.environ.get("MCTSQ_EVT_TIMING"))) for _ in range(self.halves)]
         hip, dll = _rt(), self._lib._load()
         le = LeafEval()
         addr = lambda fn: C.cast(fn, C.c_void_p).value
