@@ -126,6 +126,18 @@ class _Lib:
 lib = _Lib()
 
 
+def stream_ptr(device):
+    """hipStream_t of torch's current stream on `device` as an integer.  The raw getter costs ~0.3 us against ~4.5 us
+    for torch.cuda.current_stream(device).cuda_stream (a Stream object per call): the data-parallel step looks the
+    stream up nine times and is host-bound."""
+    import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is None:
+        return torch.cuda.current_stream(device).cuda_stream
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+    return raw(torch.cuda.current_device() if idx is None else idx)
+
+
 def ptr(t):
     """Raw device/host pointer of a torch tensor or numpy array (None -> NULL)."""
     if t is None:

@@ -351,9 +351,11 @@ static int dqn_grad_entry(const mctsq_net_desc* net, const DqnPrep* pp, const fl
     hipStream_t st = (hipStream_t)stream;
     SideStream side;
     if (side_stream(st, &side)) return -1;
-    // the helper lane starts with the gradient fill and, without prepared fragments, the backward splits: forked here.
-    // With both done elsewhere its first job waits for the head backward anyway (event `head`): no fork
-    const bool need_fork = !(upd && upd->grad_zeroed && pp);
+    // Without prepared fragments the helper lane starts with the backward splits (and the gradient fill): forked here.
+    // With prepared fragments its first job waits for the head backward anyway (event `head`), and the fill - unless a
+    // passenger of the caller's sampling launch did it - goes to the caller's stream ahead of the forward: no fork (two
+    // runtime calls of ~6-8 us each on a host-bound step)
+    const bool need_fork = !pp;
     if (need_fork) {
         MCTSQ_HIP(hipEventRecord(side.fork, st));
         MCTSQ_HIP(hipStreamWaitEvent(side.st, side.fork, 0));
@@ -438,8 +440,12 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         // the flat gradient's alignment pads must read zero; nothing touches it before the ordered reduction (step 7,
         // behind the join), so the fill rides on the helper stream instead of the critical path
         if (!(upd && upd->grad_zeroed)) {
-            MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
-            side_used = true;
+            if (pp) {
+                MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), st));
+            } else {
+                MCTSQ_HIP(hipMemsetAsync(d_grad, 0, (size_t)L.total * sizeof(float), side->st));
+                side_used = true;
+            }
         }
         if (!pp) {                                           // ... and so do the splits the backward pass multiplies by
             side_used = true;
@@ -502,7 +508,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
                                          d_target_params, pp ? pp->target : nullptr, xn, ws + P.feats_t, out_t, B, Bp, st);
         if (pr < 0) return -1;
         if (pr == 1) {
-            if (upd && upd->grad_zeroed && pp) {              // the caller skipped the fork (dqn_grad_entry): do it now
+            if (pp) {                                         // the caller skipped the fork (dqn_grad_entry): do it now
                 MCTSQ_HIP(hipEventRecord(side->fork, st));
                 MCTSQ_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
             }

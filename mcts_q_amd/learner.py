@@ -11,7 +11,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, ptr, MctsqError, StepArgs
+from ._lib import lib, ptr, stream_ptr, MctsqError, StepArgs
 from .netdesc import NetSpec
 from .parallel import all_reduce
 from .qnet import DeviceQNet
@@ -52,7 +52,7 @@ class DeviceLearner:
         self._n_sumsq = C.c_int64(0)
 
     def _st(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return stream_ptr(self.device)
 
     def _prepare(self):
         lib.check(lib.mctsq_dqn_prepare(C.byref(self.desc), ptr(self.policy.flat), ptr(self.target.flat),

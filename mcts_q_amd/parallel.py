@@ -79,10 +79,15 @@ class ShardedSampler:
     """Per-rank state of the sync-free sharded sampling: the row provision and the lagged look at the
     previous step's counters."""
 
-    def __init__(self, shard, group=None, beta: float = 0.4, bcap: int | None = None):
+    def __init__(self, shard, group=None, beta: float = 0.4, bcap: int | None = None, reuse: bool = True):
+        """reuse: the tensors of one sample() are overwritten by the next one (a training loop consumes them within
+        the step; the step is host-bound and ~20 allocations per step are a tenth of it).  Shards that do not take
+        the `reuse` keyword (test stand-ins) allocate as before."""
         self.shard, self.group, self.beta, self.bcap = shard, group, float(beta), bcap
+        self._kw = dict(reuse=True) if reuse and getattr(shard, "_reused", None) is not None else {}
         self.world, self.rank = _world(group)
         self._pending = None            # (pinned host copy of [kept, dropped], event) of the previous step
+        self._slots, self._turn = None, 0
 
     def _check_previous(self):
         if self._pending is None:
@@ -105,18 +110,21 @@ class ShardedSampler:
         B = int(u.numel())
         if self.bcap is None:
             self.bcap = draw_capacity(B, self.world)
-        allv = all_gather_rows(shard.mass_and_size(), group)      # [W, 2] on the device
+        kw = self._kw
+        allv = all_gather_rows(shard.mass_and_size(**kw), group)      # [W, 2] on the device
         masses, sizes = allv[:, 0].contiguous(), allv[:, 1].contiguous()
-        targets, draw, count = shard.shard_select(u, masses, self.rank, self.bcap)
-        batch, idx, w64, wmax = shard.sample_shard(targets, count, masses, sizes, beta=self.beta)
+        targets, draw, count = shard.shard_select(u, masses, self.rank, self.bcap, **kw)
+        batch, idx, w64, wmax = shard.sample_shard(targets, count, masses, sizes, beta=self.beta, **kw)
         if self.world > 1:
             all_reduce(wmax, dist.ReduceOp.MAX, group)
-        w = shard.normalize_weights(w64, wmax)
+        w = shard.normalize_weights(w64, wmax, **kw)
         if count.is_cuda:
-            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            if self._slots is None:                 # two (pinned words, event) pairs, used in turn: no allocation per step
+                self._slots = [(torch.empty(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+            self._turn ^= 1
+            host, ev = self._slots[self._turn]
             host.copy_(count, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
+            ev.record()
             self._pending = (host, ev)
         else:
             self._pending = (count.clone(), None)
@@ -125,7 +133,7 @@ class ShardedSampler:
 
 def sharded_sample(shard, u, group=None, beta: float = 0.4, bcap: int | None = None):
     """One-shot form of ShardedSampler.sample (tests, single calls)."""
-    return ShardedSampler(shard, group, beta, bcap).sample(u)
+    return ShardedSampler(shard, group, beta, bcap, reuse=False).sample(u)
 
 
 def allreduce_gradient(flat_grad: torch.Tensor, group=None):

@@ -11,7 +11,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ._lib import lib, ptr, MctsqError
+from ._lib import lib, ptr, stream_ptr, MctsqError
 
 ROW = 96          # floats per stored state record (91 used): price 25 | process 10x6 | gas 3x2 | pad
 
@@ -45,7 +45,7 @@ class DevicePER:
         return self.size
 
     def _st(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return stream_ptr(self.device)
 
     def _ws_for(self, B):
         need = lib.check(lib.mctsq_per_workspace_bytes(self.capacity, B))
@@ -128,6 +128,14 @@ class DevicePER:
                     nprocess=f(B, 10, 6), ngas=f(B, 3, 2), act=torch.empty(B, dtype=torch.int32, device=d),
                     rew=f(B), done=f(B))
 
+    def _reused(self, key, make):
+        """Output buffers of the shard primitives when the caller asked for reuse (parallel.ShardedSampler in a
+        steady-state loop: the results of one step are dead before the next one samples): allocated once per shape."""
+        c = self.__dict__.setdefault("_out_cache", {})
+        if key not in c:
+            c[key] = make()
+        return c[key]
+
     def _ring_ptrs(self):
         return (ptr(self.states), ptr(self.next_states), ptr(self.actions), ptr(self.rewards), ptr(self.dones))
 
@@ -155,10 +163,11 @@ class DevicePER:
         return out, w, idx, phys
 
     # ---- shard primitives (one ring = one shard of a buffer sampled as a whole; parallel.py) ------
-    def mass_and_size(self):
+    def mass_and_size(self, reuse: bool = False):
         """int64 device tensor [2] = (root of the sum-tree as a uint64 bit pattern < 2^62, live entries): the pair
         the ranks all-gather; made on the device so no host value is copied in."""
-        out = torch.empty(2, dtype=torch.int64, device=self.device)
+        mk = lambda: torch.empty(2, dtype=torch.int64, device=self.device)
+        out = self._reused("mass", mk) if reuse else mk()
         lib.check(lib.mctsq_per_total_mass(ptr(self.tree), self.capacity, self.size, ptr(out), self._st()))
         return out
 
@@ -177,26 +186,27 @@ class DevicePER:
                                               ptr(targets), ptr(mine), self._st()))
         return targets, mine
 
-    def shard_select(self, u, shard_mass, rank: int, bcap: int):
+    def shard_select(self, u, shard_mass, rank: int, bcap: int, reuse: bool = False):
         """This rank's share of the global draws `u`, compacted on the device: (targets int64 [bcap], draw
         positions int32 [bcap] (-1 = padding), count int32 [2] = (kept, dropped))."""
         u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
-        targets = torch.empty(bcap, dtype=torch.int64, device=self.device)
-        draw = torch.empty(bcap, dtype=torch.int32, device=self.device)
-        count = torch.empty(2, dtype=torch.int32, device=self.device)
+        mk = lambda: (torch.empty(bcap, dtype=torch.int64, device=self.device),
+                      torch.empty(bcap, dtype=torch.int32, device=self.device),
+                      torch.empty(2, dtype=torch.int32, device=self.device))
+        targets, draw, count = self._reused(("select", bcap), mk) if reuse else mk()
         lib.check(lib.mctsq_per_shard_select(ptr(u), u.numel(), ptr(shard_mass), shard_mass.numel(), int(rank),
                                              int(bcap), ptr(targets), ptr(draw), ptr(count), self._st()))
         return targets, draw, count
 
-    def sample_shard(self, targets, count, shard_mass, shard_size, beta: float = 0.4):
+    def sample_shard(self, targets, count, shard_mass, shard_size, beta: float = 0.4, reuse: bool = False):
         """bcap rows at the compacted targets, totals from the all-gathered device arrays, transitions gathered
         in the same launch: (batch, logical idx (-1 = padding), raw fp64 weights, local max fp64 [1])."""
         bcap = targets.numel()
-        idx = torch.empty(bcap, dtype=torch.int64, device=self.device)
-        phys = torch.empty(bcap, dtype=torch.int64, device=self.device)
-        w64 = torch.empty(bcap, dtype=torch.float64, device=self.device)
-        wmax = torch.empty(1, dtype=torch.float64, device=self.device)
-        out = self._batch_tensors(bcap)
+        mk = lambda: (torch.empty(bcap, dtype=torch.int64, device=self.device),
+                      torch.empty(bcap, dtype=torch.int64, device=self.device),
+                      torch.empty(bcap, dtype=torch.float64, device=self.device),
+                      torch.empty(1, dtype=torch.float64, device=self.device), self._batch_tensors(bcap))
+        idx, phys, w64, wmax, out = self._reused(("sample", bcap), mk) if reuse else mk()
         ws = self._ws_for(1)
         lib.check(lib.mctsq_per_sample_shard(ptr(self.tree), ptr(self.prio), self.capacity, self.head, self.size,
                                              ptr(targets), ptr(count), bcap, self.alpha, beta, self.mass_capacity,
@@ -221,8 +231,9 @@ class DevicePER:
                                               self._st()))
         return idx, phys, w64, wmax
 
-    def normalize_weights(self, w64, wmax):
-        w = torch.empty(w64.numel(), dtype=torch.float32, device=self.device)
+    def normalize_weights(self, w64, wmax, reuse: bool = False):
+        mk = lambda: torch.empty(w64.numel(), dtype=torch.float32, device=self.device)
+        w = self._reused(("norm", w64.numel()), mk) if reuse else mk()
         lib.check(lib.mctsq_per_normalize_weights(ptr(w64), w64.numel(), ptr(wmax), ptr(w), self._st()))
         return w
 

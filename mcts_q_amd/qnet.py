@@ -11,12 +11,12 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import lib, ptr, MctsqError
+from ._lib import lib, ptr, stream_ptr, MctsqError
 from .netdesc import NetSpec
 
 
 def _stream_ptr(device):
-    return torch.cuda.current_stream(device).cuda_stream
+    return stream_ptr(device)
 
 
 class DeviceQNet:
