@@ -142,6 +142,7 @@ def ptr(t):
     """Raw device/host pointer of a torch tensor or numpy array (None -> NULL)."""
     if t is None:
         return None
-    if hasattr(t, "data_ptr"):
+    try:
         return t.data_ptr()
-    return t.ctypes.data
+    except AttributeError:
+        return t.ctypes.data

@@ -137,7 +137,12 @@ class DevicePER:
         return c[key]
 
     def _ring_ptrs(self):
-        return (ptr(self.states), ptr(self.next_states), ptr(self.actions), ptr(self.rewards), ptr(self.dones))
+        rp = self.__dict__.get("_ring_ptr_cache")
+        if rp is None or rp[0] is not self.states:           # the ring tensors live as long as the buffer
+            rp = (self.states, (ptr(self.states), ptr(self.next_states), ptr(self.actions), ptr(self.rewards),
+                                ptr(self.dones)))
+            self._ring_ptr_cache = rp
+        return rp[1]
 
     @staticmethod
     def _batch_ptrs(out):
