@@ -366,7 +366,7 @@ def main():
         from mcts_q_amd.treesearch import LockstepMCTS
 
         benv = PtGBatchEnv(synthetic_ptg_kwargs(0, scale=1.0, train_days=46, env_values=dict(eps_len_d=40)), seed=rank)
-        K, iters, tsteps = args.trees, 50, 5
+        K, iters, tsteps = args.trees, 50, 10
         halves = 2 if K >= 64 else 1
         drv = LockstepMCTS(K, DeviceLeafEvaluator(net, -(-K // halves), halves, zero_copy=True), iters, 42, 19652, 1.25,
                            batch_env=benv, seed=rank)

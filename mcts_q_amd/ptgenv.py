@@ -42,7 +42,7 @@ _LIB = None
 def _lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmctsq_tree.so")
+        path = os.environ.get("MCTSQ_TREE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmctsq_tree.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with make -C mcts_q_amd/csrc")
         L = C.CDLL(path)

@@ -131,7 +131,7 @@ def _tree_lib():
     global _TREE_LIB
     if _TREE_LIB is None:
         import ctypes
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmctsq_tree.so")
+        path = os.environ.get("MCTSQ_TREE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmctsq_tree.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with make -C mcts_q_amd/csrc")
         L = ctypes.CDLL(path)
