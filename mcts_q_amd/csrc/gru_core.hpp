@@ -60,6 +60,21 @@ struct GruWave {
     float ab2, lnwj, lnbj;          // score bias (log2 units), LayerNorm scale / shift of unit j: fetched with the weights
     int lane, wq, jl, q, j, FP;
     unsigned nsync;
+    // SAVE: running pointers of this wave's slice of the training record (advanced by one step's stride per step) and
+    // of the score rows.  Computed from t and looked up through the slot record per step, the addresses cost 64-bit
+    // multiplies and - worse - a scalar load of the score pointer inside the step, whose wait also drains the LDS
+    // reads the step keeps in flight.
+    float *rp_r, *rp_z, *rp_n, *rp_hn, *rp_h, *rp_sc;
+    int64_t rec_stride, sc_stride;
+    __device__ __forceinline__ void bind_records(const GruSlot& s, int64_t row0, int64_t Bp) {
+        if (!SAVE) return;
+        const int64_t ub0 = ((row0 / TILE) * 4 + wq) * 256;
+        rp_r = s.sv_r + ub0; rp_z = s.sv_z + ub0; rp_n = s.sv_n + ub0; rp_hn = s.sv_hn + ub0;
+        rp_h = s.sv_h + ub0 + Bp * E;
+        rp_sc = s.sv_score + row0;
+        rec_stride = (Bp / TILE) * 4 * 256;
+        sc_stride = Bp;
+    }
 
     __device__ __forceinline__ void bind(int lane_, int wq_) {
         lane = lane_; wq = wq_; jl = lane & 15; q = lane >> 4; j = 16 * wq + jl;
@@ -244,7 +259,10 @@ struct GruWave {
         if (SAVE) {                                           // the four rows' scores (log2 units) as one 16-byte store
             const f32x4 sc4 = {(p[0][0] + p[1][0]) + (p[2][0] + p[3][0]), (p[0][1] + p[1][1]) + (p[2][1] + p[3][1]),
                                (p[0][2] + p[1][2]) + (p[2][2] + p[3][2]), (p[0][3] + p[1][3]) + (p[2][3] + p[3][3])};
-            if (live && wq == 0 && jl == 0) *reinterpret_cast<f32x4*>(&s.sv_score[(int64_t)t * Bp + row0 + 4 * q]) = sc4;
+            if (live) {                                       // wave-uniform; live folds come in step order 0, 1, 2, ...
+                if (wq == 0 && jl == 0) *reinterpret_cast<f32x4*>(rp_sc + 4 * q) = sc4;
+                rp_sc += sc_stride;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -278,6 +296,7 @@ struct GruWave {
         else flush_<BND, 1>(s, L, row0, Bp);
     }
     __device__ __forceinline__ void run(const GruSlot& s, GruLds& L, int64_t row0, int64_t Bp) {
+        bind_records(s, row0, Bp);
         if (FP == 8) { if (bounded) run_<true, true>(s, L, row0, Bp); else run_<true, false>(s, L, row0, Bp); }
         else { if (bounded) run_<false, true>(s, L, row0, Bp); else run_<false, false>(s, L, row0, Bp); }
     }
@@ -350,11 +369,10 @@ struct GruWave {
         // vector address math.  Each field leaves as soon as it exists (r, z here, under the n gate's products; n, W_hn h
         // and h at the end): five stores back to back from every wave of the CU at once queued up in the memory pipe
         // and the last wave's issue stalled behind them on the step's critical path.
-        const int64_t ub = SAVE ? (((int64_t)t * (Bp / TILE) + row0 / TILE) * 4 + wq) * 256 : 0;
         const int lo = lane * 4;
         if (SAVE) {
-            *reinterpret_cast<f32x4*>(s.sv_r + ub + lo) = (f32x4){rg[0], rg[1], rg[2], rg[3]};
-            *reinterpret_cast<f32x4*>(s.sv_z + ub + lo) = (f32x4){zg[0], zg[1], zg[2], zg[3]};
+            *reinterpret_cast<f32x4*>(rp_r + lo) = (f32x4){rg[0], rg[1], rg[2], rg[3]};
+            *reinterpret_cast<f32x4*>(rp_z + lo) = (f32x4){zg[0], zg[1], zg[2], zg[3]};
         }
         f32x4 svn, svhn, svh;
 #pragma unroll
@@ -372,9 +390,10 @@ struct GruWave {
             hh[cur][r] = hnew;
         }
         if (SAVE) {
-            *reinterpret_cast<f32x4*>(s.sv_n + ub + lo) = svn;
-            *reinterpret_cast<f32x4*>(s.sv_hn + ub + lo) = svhn;
-            *reinterpret_cast<f32x4*>(s.sv_h + ub + Bp * E + lo) = svh;
+            *reinterpret_cast<f32x4*>(rp_n + lo) = svn;
+            *reinterpret_cast<f32x4*>(rp_hn + lo) = svhn;
+            *reinterpret_cast<f32x4*>(rp_h + lo) = svh;
+            rp_r += rec_stride; rp_z += rec_stride; rp_n += rec_stride; rp_hn += rec_stride; rp_h += rec_stride;
         }
     }
 
