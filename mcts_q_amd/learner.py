@@ -190,4 +190,7 @@ class DeviceLearner:
     def update_target(self, tau: float = 1.0):
         lib.check(lib.mctsq_polyak(ptr(self.policy.flat), ptr(self.target.flat), self.spec.n_flat, float(tau),
                                    self._st()))
-        self._prepare()
+        # the target's fragments are stale now; whoever needs them next re-splits (the next step() does it as a
+        # passenger of its sampling launch, compute_grad() through _ensure_prepared())
+        self._prep_versions = None
+        self.target._prep_version = None
