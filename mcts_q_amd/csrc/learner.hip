@@ -406,7 +406,7 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
     // The hidden states the pooling backward multiplies by start their trip here, all at once and without a condition
     // around the loads (index clamped instead): fetched in rounds of eight behind the LayerNorm part, each round was
     // one more exposed memory round trip (four for the 25-step window) before the first BPTT step could start.
-    constexpr int HB = RPL == 2 ? 32 : 8;                      // RPL 4: eight in flight keep the kernel under 256 registers
+    constexpr int HB = RPL == 2 ? 32 : 8;                      // RPL 4: 32 registers of records in flight, as before
     RowVec<RPL> hv[HB];
 #pragma unroll
     for (int u = 0; u < HB; ++u) hv[u] = rec(s.sv_h, (u < S ? u : S - 1) + 1);
