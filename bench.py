@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-ms", type=float, default=300.0, dest="settle_ms",
+                    help="untimed device load ahead of the warm-up steps, until the clocks have settled")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--train-batch", type=int, default=1024, help="GLOBAL train batch (split over ranks)")
     ap.add_argument("--replay", type=int, default=1_000_000, help="replay entries per rank")
@@ -218,6 +220,13 @@ def main():
             return float(t.item())
         return x
 
+    # clock settle: the device ramps its clocks over the first tenths of a second of load; a 20-step run on a cold
+    # device read 43 us per launch against 39.5-41 in steady state.  Untimed, like the W warm-up steps behind it.
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(50):
+            net(price, process, gas, out=out)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         net(price, process, gas, out=out)
     # --- timed region: exactly K steps ---------------------------------------------------------
@@ -389,7 +398,8 @@ def main():
         res = {
             "metric": "Q leaf evals/sec (gru/gru/gru, batch 4096 per GPU)",
             "value": world * B * args.steps / wall, "unit": "leaf evals/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "steps": args.steps, "warmup": args.warmup, "clock_settle_ms": args.settle_ms,
+            "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic U[0,1) windows, seeded default-init weights",
             "config": {"workload": "BASELINE config 2: GRU encoder batched leaf evaluation, "
