@@ -135,6 +135,12 @@ typedef struct {
     float *stage[4], *dev_in[4], *q[4], *vmax[4], *prior[4];
     int32_t* argmax[4];
     void *ws[4], *event[4];
+    /* optional: completion through a word in pinned host memory instead of an event.  stream_write32 =
+     * hipStreamWriteValue32 (or a host function of that shape): behind every leaf batch of block h the stream writes the
+     * next sequence number to *done_flag[h] (4-byte aligned, device-accessible host memory; its current value is the
+     * starting point), and the search waits by reading that word.  NULL: event_record / event_sync as above. */
+    void* stream_write32;
+    uint32_t* done_flag[4];
 } mctsq_leaf_eval;
 int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, double c_base, double c_init,
                               uint64_t seed, uint64_t iteration0, int64_t iterations, double noise_sigma,

@@ -184,6 +184,26 @@ typedef int (*forward_fn)(const void*, const float*, const void*, const float*, 
 typedef int (*event_record_fn)(void*, void*);
 typedef int (*event_sync_fn)(void*);
 typedef int (*memcpy_fn)(void*, const void*, size_t, int, void*);
+typedef int (*write32_fn)(void*, void*, uint32_t, unsigned);
+
+/* wait until the stream has written `want` to the pinned word (mctsq_leaf_eval.done_flag); gives up after ~20 s */
+static int wait_flag(const uint32_t* flag, uint32_t want) {
+    for (int64_t spin = 0;; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) return 0;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if ((spin & 0xFFFFF) == 0xFFFFF) {
+            static const double LIMIT = 20.0;
+            static __thread double t_start = 0.0;
+            struct timespec t;
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            const double now = (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+            if (spin == 0xFFFFF) t_start = now;
+            else if (now - t_start > LIMIT) return 9999;
+        }
+    }
+}
 
 static inline double now_s(void) {
     struct timespec t;
@@ -202,6 +222,13 @@ int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, do
     const event_record_fn ev_record = (event_record_fn)ev->event_record;
     const event_sync_fn ev_sync = (event_sync_fn)ev->event_sync;
     const memcpy_fn copy = (memcpy_fn)ev->memcpy_async;
+    const write32_fn write32 = (write32_fn)ev->stream_write32;
+    uint32_t seq[4] = {0, 0, 0, 0};
+    if (write32)
+        for (int64_t h = 0; h < nh; ++h) {
+            if (!ev->done_flag[h]) return -3;
+            seq[h] = *ev->done_flag[h];
+        }
     double t_wait = 0, t_backup = 0, t_expand = 0, t_launch = 0;
     int64_t rc = 0;
     for (int64_t it = 0; it <= iterations && rc == 0; ++it) {          /* the extra round only drains */
@@ -211,7 +238,7 @@ int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, do
             if (pend[h] >= 0) {
                 double t0 = prof ? now_s() : 0.0;
                 if (pend[h] > 0) {
-                    const int e = ev_sync(ev->event[h]);
+                    const int e = write32 ? wait_flag(ev->done_flag[h], seq[h]) : ev_sync(ev->event[h]);
                     if (e) { rc = -1000 - e; break; }
                 }
                 double t1 = prof ? now_s() : 0.0;
@@ -235,7 +262,7 @@ int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, do
                 if (!e)
                     e = forward(ev->net, ev->params, ev->prep, in, in + cap * P, in + cap * (P + L6), n_new, ev->q[h],
                                 ev->vmax[h], ev->argmax[h], ev->prior[h], ev->ws[h], ev->ws_bytes, ev->stream[h], NULL);
-                if (!e) e = ev_record(ev->event[h], ev->stream[h]);
+                if (!e) e = write32 ? write32(ev->stream[h], ev->done_flag[h], ++seq[h], 0u) : ev_record(ev->event[h], ev->stream[h]);
                 if (e) { rc = -1000 - (e < 0 ? -e : e); break; }
             }
             pend[h] = n_new;
@@ -244,7 +271,7 @@ int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, do
     }
     if (rc != 0)                                            /* leave nothing in flight behind an error */
         for (int64_t h = 0; h < nh; ++h)
-            if (pend[h] > 0) ev_sync(ev->event[h]);
+            if (pend[h] > 0) { if (write32) wait_flag(ev->done_flag[h], seq[h]); else ev_sync(ev->event[h]); }
     if (prof) { prof[0] += t_wait; prof[1] += t_backup; prof[2] += t_expand; prof[3] += t_launch; }
     return rc;
 }

@@ -150,6 +150,16 @@ class DeviceLeafEvaluator:
             le.vmax[h] = self._hout[h].data_ptr()
             le.prior[h] = self._hout[h].data_ptr() + 4 * self.cap
             le.event[h] = self._hipev[h].ptr
+        # completion through a pinned word the stream writes behind each leaf batch (hipStreamWriteValue32) and the
+        # search loop reads, instead of an event record + hipEventSynchronize per batch (MCTSQ_SEARCH_EVENTS=1: events)
+        import os
+        wr = getattr(hip, "hipStreamWriteValue32", None)
+        if wr is not None and not os.environ.get("MCTSQ_SEARCH_EVENTS"):
+            if not hasattr(self, "_flags"):
+                self._flags = torch.zeros(16 * self.halves, dtype=torch.int32, pin_memory=True)   # one cache line each
+            le.stream_write32 = addr(wr)
+            for h in range(self.halves):
+                le.done_flag[h] = self._flags.data_ptr() + 64 * h
         self._le = le                                                   # keeps the desc byref alive with it
         return le
 

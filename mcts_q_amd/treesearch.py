@@ -81,7 +81,8 @@ class LeafEval(ctypes.Structure):
     _fields_ = ([(k, ctypes.c_void_p) for k in ("forward", "event_record", "event_sync", "memcpy_async", "net", "params",
                                                 "prep")] + [("stream", ctypes.c_void_p * 4)] +
                 [(k, ctypes.c_int64) for k in ("halves", "cap", "ws_bytes", "n_act")] +
-                [(k, ctypes.c_void_p * 4) for k in ("stage", "dev_in", "q", "vmax", "prior", "argmax", "ws", "event")])
+                [(k, ctypes.c_void_p * 4) for k in ("stage", "dev_in", "q", "vmax", "prior", "argmax", "ws", "event")] +
+                [("stream_write32", ctypes.c_void_p), ("done_flag", ctypes.c_void_p * 4)])
 
 
 class HostStagedEvaluator:
