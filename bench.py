@@ -135,15 +135,18 @@ BF16_MATRIX_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
 
 
 def executed_pipe_peak(spec):
-    """Ceiling of the instructions the kernel actually issues, in fp32-equivalent TFLOP/s: the recurrent products and
-    the head run as SIX bf16 MFMAs per fp32 product (2500 / 6 = 417), the input projections as fp32 MFMA (157.3);
-    the two shares are weighted by the time each would take at its own peak."""
+    """Ceiling of the instructions the kernel actually issues, in fp32-equivalent TFLOP/s: the recurrent products run
+    as THREE fp16 MFMAs per fp32 product (two-way split: 2500 / 3 = 833), the head as SIX bf16 MFMAs (three-way split:
+    2500 / 6 = 417), the input projections as fp32 MFMA (157.3); the shares are weighted by the time each would take
+    at its own peak.  Returns (ceiling, share of the FLOPs on the 16-bit matrix instructions)."""
     enc, head = forward_flops(spec)
-    fp32 = sum(S * 2 * 192 * F for kind, S, F in zip((spec.price, spec.process, spec.gas), spec.seq, spec.feat_dims)
-               if kind == "gru")
+    gru = [(S, F) for kind, S, F in zip((spec.price, spec.process, spec.gas), spec.seq, spec.feat_dims) if kind == "gru"]
+    fp32 = sum(S * 2 * 192 * F for S, F in gru)
+    rec = sum(S * 2 * 192 * 64 for S, F in gru)
     total = enc + head
-    fb = (total - fp32) / total
-    return 1.0 / (fb / (BF16_MATRIX_PEAK_TFLOPS / 6.0) + (1.0 - fb) / FP32_MATRIX_PEAK_TFLOPS), fb
+    six = total - fp32 - rec                      # head (and whatever else the encoders multiply: none for gru/gru/gru)
+    t = rec / (BF16_MATRIX_PEAK_TFLOPS / 3.0) + six / (BF16_MATRIX_PEAK_TFLOPS / 6.0) + fp32 / FP32_MATRIX_PEAK_TFLOPS
+    return total / t, (rec + six) / total
 
 
 def main():
@@ -270,13 +273,14 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_GBs_algorithmic": alg_bytes / (k_ms * 1e-3) / 1e9,
                 "frac_executed_pipe": achieved / pipe_peak, "executed_pipe_peak": pipe_peak,
-                "bf16_split_share_of_flops": bf16_share,
+                "split_16bit_share_of_flops": bf16_share,
                 "mfma_busy_measured": prof["mfma_busy"], "mfma_busy_source": prof["mfma_busy_source"],
                 "note": "intensity ~2.5 kFLOP/B: matrix/vector issue bounds it, not HBM.  `frac` = ALGORITHMIC fp32 "
-                        "FLOPs / time against the dense fp32 MFMA peak (157.3).  The recurrent products and the head "
-                        "execute as six bf16 MFMAs on an exact 3-way split of both operands (fp32-accurate), whose "
-                        "ceiling is 2500/6 = 417 TFLOP/s fp32-equivalent; `frac_executed_pipe` prices the kernel against "
-                        "that ceiling blended with the fp32-MFMA share (input projections)"}
+                        "FLOPs / time against the dense fp32 MFMA peak (157.3).  The recurrent products execute as three "
+                        "fp16 MFMAs on a two-way split of operands scaled into the fp16 range (ceiling 2500/3 = 833 "
+                        "TFLOP/s fp32-equivalent), the head as six bf16 MFMAs on an exact 3-way split (2500/6 = 417), "
+                        "both fp32-accurate; `frac_executed_pipe` prices the kernel against those ceilings blended "
+                        "with the fp32-MFMA share (input projections)"}
 
     # --- the same K steps with the D2H of value / greedy action inside the timed region: the kernel's
     # epilogue stores vmax / argmax straight into pinned (device-mapped) host memory, so the transfer is part of the

@@ -61,6 +61,43 @@ __device__ __forceinline__ void split8(const float4& x0, const float4& x1, u32x4
     }
 }
 
+// ---- split-fp16 matrix arithmetic for operands of known magnitude (the GRU recurrence: |h| <= 1, W_hh scaled per row) ----
+// A value scaled into the upper fp16 range is hi + lo with hi = fp16(x) (round to nearest, 11 significant bits)
+// and lo = fp16(x - hi) (the difference is exact in fp32; lo carries the next 11 bits): x to ~2^-23 relative, i.e.
+// fp32 accuracy, in TWO planes, so a product needs the three terms hi*hi, hi*lo, lo*hi (lo*lo is below 2^-22 of
+// the product) -- half the matrix instructions of the three-plane bf16 split.  fp16 has 5 exponent bits: the caller
+// scales by a power of two (exact) so that the largest magnitude sits near 2^14; a value 2^-17 of that still has
+// a normal lo, smaller ones lose relative accuracy only where their contribution is below 2^-28 of the largest.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int F16_TOP = 14;                  // scaled magnitudes stay below 2^(F16_TOP + 1)
+__device__ __forceinline__ f32x4 mfma_h(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split2h(float xs, unsigned short& hi, unsigned short& lo) {
+    const _Float16 h = (_Float16)xs;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (_Float16)(xs - (float)h));
+}
+// 8 consecutive (already scaled) fp32 -> two packed fp16x8 planes (element e in bits 16(e&1) of word e>>1)
+__device__ __forceinline__ void split8h(const float4& x0, const float4& x1, u32x4& hi, u32x4& lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned short h0, l0, h1, l1;
+        split2h(x[2 * p], h0, l0);
+        split2h(x[2 * p + 1], h1, l1);
+        hi[p] = (unsigned)h0 | ((unsigned)h1 << 16); lo[p] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+}
+// power of two 2^e as a float, e in [-126, 127]
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+// the power-of-two exponent that brings a row of largest magnitude `amax` into [2^F16_TOP, 2^(F16_TOP+1))
+__device__ __forceinline__ int f16_row_shift(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;      // floor(log2 amax) for normal amax
+    const int sh = amax > 0.0f ? F16_TOP - e : 0;
+    return sh < -100 ? -100 : (sh > 40 ? 40 : sh);
+}
+
 // DPP move within rows of 16 lanes (row_ror:n = 0x120 + n)
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float v) {

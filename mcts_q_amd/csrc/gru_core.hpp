@@ -4,12 +4,15 @@
 // One "group" = 4 waves (256 lanes) advancing one 16-sample tile of one encoder slot; wave wq of the
 // group owns hidden units 16wq..16wq+15.  Per step every wave computes its 3 gate tiles
 // [16 samples x 16 units] = [x_t | h_{t-1}] . [W_ih | W_hh]^T.  The input projection (K <= 8) uses
-// v_mfma_f32_16x16x4_f32 (exact fp32).  The recurrent product (K = 64) uses the 16x-faster bf16
-// matrix instruction on a three-way split of both operands: every fp32 value is the exact sum of
-// three bf16 numbers (hi + mid + lo, 8 mantissa bits each), and the six largest of the nine cross
-// products are accumulated in fp32 -- the three dropped ones are below 2^-23 of the product, i.e.
-// under one fp32 ulp; measured error against an fp64 evaluation is smaller than that of a plain
-// fp32 fma chain (tests/test_gpu_qnet.py).  W fragments (pre-split) stay resident in VGPRs, h is
+// v_mfma_f32_16x16x4_f32 (exact fp32).  The recurrent product (K = 64) uses the 16x-faster fp16
+// matrix instruction on a two-way split of both operands (device_utils.hpp: split2h): |h| <= 1 and the
+// rows of W_hh are scaled by powers of two into the upper fp16 range, where hi + lo carries 22+ bits of
+// the value, and the three cross products hi*hi, hi*lo, lo*hi are accumulated in fp32 -- the dropped
+// lo*lo is below 2^-22 of the product; measured error against an fp64 evaluation is that of a plain
+// fp32 fma chain (tests/test_gpu_qnet.py).  The accumulators of unit j therefore hold 2^k_j times the
+// gate pre-activation (k_j = 14 + the row's shift): biases and input-projection weights are scaled by
+// the same power of two when they are fetched and the constant inside the gate's exp2 argument by its
+// inverse, all exact, so the step has no instruction for it.  W fragments (pre-split) stay resident in VGPRs, h is
 // split by the lane that produces it and exchanged through double-buffered LDS planes.  The four waves of
 // a group synchronise through an arrival counter in LDS (GruWave::sync), NOT the workgroup barrier,
 // so groups of different window length that share a workgroup advance independently and the short
@@ -27,7 +30,7 @@ constexpr int HLD = 72;     // LDS row stride of an h plane (bf16 elements): 144
 constexpr int XLD = 132;    // LDS row stride of the staged window: >= S * (4 or 8)
 
 struct GruLds {             // per-group LDS carve-out
-    unsigned short hb[3][2][TILE * HLD];   // h planes (hi, mid, lo) x double buffer, bf16 bits
+    unsigned short hb[2][2][TILE * HLD];   // planes (hi, lo) of 2^14 h x double buffer, fp16 bits
     float xs[TILE * XLD];
     float spart[2][4][TILE];
     float dump[4][64 * 4];  // write-only sink of the non-publishing lanes (GruWave::publish)
@@ -48,7 +51,8 @@ __device__ __forceinline__ void group_sync(unsigned* ctr, unsigned target, int l
 
 template <bool SAVE>
 struct GruWave {
-    u32x4 whi[3][2], wmid[3][2], wlo[3][2];   // W_hh[g*64 + j][32c + 8q .. +7], gate g, K chunk c, split
+    u32x4 whi[3][2], wlo[3][2];     // 2^sh W_hh[g*64 + j][32c + 8q .. +7], gate g, K chunk c, split-fp16
+    float esr, esz, esn, invn;      // exp2-argument constants of the three gates with 2^-k of unit j folded in; 2^-k_n
     float wir[2], wiz[2], win[2];   // W_ih[g*64 + j][q (+4)], zero padded
     f32x4 brv, bzv, binv, bhnv;     // gate biases replicated over the 4 accumulator rows: the accumulators START from them
     float awj, abl;                 // score weight of unit j (log2 units); the score bias rides on one lane's product
@@ -89,26 +93,30 @@ struct GruWave {
     __device__ __forceinline__ void init_weights(const GruSlot& s) {
         const int F = s.F;
         FP = F > 4 ? 8 : 4;
-        const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep) + (int64_t)wq * (3 * 2 * 3 * 64) + lane;
+        const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep) + (int64_t)wq * (3 * 2 * 2 * 64) + lane;
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                whi[g][c] = wp[((g * 2 + c) * 3 + 0) * 64];
-                wmid[g][c] = wp[((g * 2 + c) * 3 + 1) * 64];
-                wlo[g][c] = wp[((g * 2 + c) * 3 + 2) * 64];
+                whi[g][c] = wp[((g * 2 + c) * 2 + 0) * 64];
+                wlo[g][c] = wp[((g * 2 + c) * 2 + 1) * 64];
             }
+        // unit j's accumulators carry 2^k times the pre-activation (k per gate row, written by prep_gru_fwd)
+        const int* kp = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.wprep) + GRU_FWD_FRAG_BYTES);
+        const int kr = kp[j], kz = kp[E + j], kn = kp[2 * E + j];
+        const float pr = pow2i(kr), pz = pow2i(kz), pn = pow2i(kn);
+        esr = -LOG2E * pow2i(-kr); esz = -LOG2E * pow2i(-kz); esn = (2.0f * LOG2E) * pow2i(-kn); invn = pow2i(-kn);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int k = q + 4 * ks;
             const bool ok = k < F;
-            wir[ks] = ok ? s.wih[(int64_t)(0 * E + j) * F + k] : 0.0f;
-            wiz[ks] = ok ? s.wih[(int64_t)(1 * E + j) * F + k] : 0.0f;
-            win[ks] = ok ? s.wih[(int64_t)(2 * E + j) * F + k] : 0.0f;
+            wir[ks] = ok ? s.wih[(int64_t)(0 * E + j) * F + k] * pr : 0.0f;
+            wiz[ks] = ok ? s.wih[(int64_t)(1 * E + j) * F + k] * pz : 0.0f;
+            win[ks] = ok ? s.wih[(int64_t)(2 * E + j) * F + k] * pn : 0.0f;
         }
         {
-            const float br = s.bih[j] + s.bhh[j], bz = s.bih[E + j] + s.bhh[E + j];
-            const float bin = s.bih[2 * E + j], bhn = s.bhh[2 * E + j];
+            const float br = (s.bih[j] + s.bhh[j]) * pr, bz = (s.bih[E + j] + s.bhh[E + j]) * pz;
+            const float bin = s.bih[2 * E + j] * pn, bhn = s.bhh[2 * E + j] * pn;
             brv = (f32x4){br, br, br, br}; bzv = (f32x4){bz, bz, bz, bz};
             binv = (f32x4){bin, bin, bin, bin}; bhnv = (f32x4){bhn, bhn, bhn, bhn};
         }
@@ -171,7 +179,7 @@ struct GruWave {
         const int n = TILE * SFd;                             // <= 16 * 32 * 8 = 4096
         // everything that does not need the loaded elements first
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < 2; ++pl)
             for (int idx = gtid; idx < TILE * HLD / 2; idx += 256) reinterpret_cast<unsigned*>(L.hb[pl][0])[idx] = 0u;
         if (gtid < 64) L.spart[0][gtid >> 4][gtid & 15] = gtid < 16 ? ab2 : 0.0f;   // score of h_{-2}: ab
         if (first && gtid == 0) L.arrivals = 0;
@@ -317,15 +325,14 @@ struct GruWave {
     template <bool FP8, bool BND, int PAR>
     __device__ __forceinline__ void step(const GruSlot& s, GruLds& L, int t, int64_t row0, int64_t Bp) {
         constexpr int cur = PAR, nxt = PAR ^ 1;
-        // A fragments of h_{t-1}: plane pl, K chunk c -> 8 bf16 of row lane&15 at k = 32c + 8q
-        u32x4 ah[2], am[2], al[2];
+        // A fragments of 2^14 h_{t-1}: plane pl, K chunk c -> 8 fp16 of row lane&15 at k = 32c + 8q
+        u32x4 ah[2], al[2];
         {
             const int o = (lane & 15) * HLD + 8 * q;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 ah[c] = *reinterpret_cast<const u32x4*>(&L.hb[0][cur][o + 32 * c]);
-                am[c] = *reinterpret_cast<const u32x4*>(&L.hb[1][cur][o + 32 * c]);
-                al[c] = *reinterpret_cast<const u32x4*>(&L.hb[2][cur][o + 32 * c]);
+                al[c] = *reinterpret_cast<const u32x4*>(&L.hb[1][cur][o + 32 * c]);
             }
         }
         const float* xa = &L.xs[(lane & 15) * XLD + t * (FP8 ? 8 : 4) + q];
@@ -338,31 +345,25 @@ struct GruWave {
         if (FP8) {
             accr = mfma16(x1, wir[1], accr); accz = mfma16(x1, wiz[1], accz); acci = mfma16(x1, win[1], acci);
         }
-        // recurrent product: six split terms per K chunk, smallest first; r and z chains alternate
-#define T6(ACC0, ACC1, G0, G1, C)                                                              \
-        ACC0 = mfma_bf(al[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(al[C], whi[G1][C], ACC1);    \
-        ACC0 = mfma_bf(ah[C], wlo[G0][C], ACC0);  ACC1 = mfma_bf(ah[C], wlo[G1][C], ACC1);    \
-        ACC0 = mfma_bf(am[C], wmid[G0][C], ACC0); ACC1 = mfma_bf(am[C], wmid[G1][C], ACC1);   \
-        ACC0 = mfma_bf(am[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(am[C], whi[G1][C], ACC1);    \
-        ACC0 = mfma_bf(ah[C], wmid[G0][C], ACC0); ACC1 = mfma_bf(ah[C], wmid[G1][C], ACC1);   \
-        ACC0 = mfma_bf(ah[C], whi[G0][C], ACC0);  ACC1 = mfma_bf(ah[C], whi[G1][C], ACC1);
-        T6(accr, accz, 0, 1, 0)
-        T6(accr, accz, 0, 1, 1)
-#undef T6
+        // recurrent product: three split terms per K chunk, smallest first; r and z chains alternate
+#define T3(ACC0, ACC1, G0, G1, C)                                                              \
+        ACC0 = mfma_h(al[C], whi[G0][C], ACC0);  ACC1 = mfma_h(al[C], whi[G1][C], ACC1);      \
+        ACC0 = mfma_h(ah[C], wlo[G0][C], ACC0);  ACC1 = mfma_h(ah[C], wlo[G1][C], ACC1);      \
+        ACC0 = mfma_h(ah[C], whi[G0][C], ACC0);  ACC1 = mfma_h(ah[C], whi[G1][C], ACC1);
+        T3(accr, accz, 0, 1, 0)
+        T3(accr, accz, 0, 1, 1)
+#undef T3
         publish(L, hh[nxt], nxt);                             // pooling, two steps behind: scores of h_{t-1}
         attend<BND>(s, sp, hh[cur], t >= 2, t >= 2 ? t - 2 : 0, row0, Bp);   // ... and the fold of h_{t-2}
         // n gate: K chunk 0 into accn (on top of b_hn), chunk 1 into accm (two independent chains)
-        f32x4 accn = mfma_bf(al[0], whi[2][0], bhnv), accm = mfma_bf(al[1], whi[2][1], (f32x4){0, 0, 0, 0});
-        accn = mfma_bf(ah[0], wlo[2][0], accn);  accm = mfma_bf(ah[1], wlo[2][1], accm);
-        accn = mfma_bf(am[0], wmid[2][0], accn); accm = mfma_bf(am[1], wmid[2][1], accm);
-        accn = mfma_bf(am[0], whi[2][0], accn);  accm = mfma_bf(am[1], whi[2][1], accm);
-        accn = mfma_bf(ah[0], wmid[2][0], accn); accm = mfma_bf(ah[1], wmid[2][1], accm);
-        accn = mfma_bf(ah[0], whi[2][0], accn);  accm = mfma_bf(ah[1], whi[2][1], accm);
+        f32x4 accn = mfma_h(al[0], whi[2][0], bhnv), accm = mfma_h(al[1], whi[2][1], (f32x4){0, 0, 0, 0});
+        accn = mfma_h(ah[0], wlo[2][0], accn);  accm = mfma_h(ah[1], wlo[2][1], accm);
+        accn = mfma_h(ah[0], whi[2][0], accn);  accm = mfma_h(ah[1], whi[2][1], accm);
         float rg[4], zg[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            rg[r] = sigmoid_fast(accr[r]);
-            zg[r] = sigmoid_fast(accz[r]);
+            rg[r] = fast_rcp(1.0f + fast_exp2(esr * accr[r]));      // sigmoid of 2^-k accr
+            zg[r] = fast_rcp(1.0f + fast_exp2(esz * accz[r]));
         }
         // training record, lane-major (kernels.hpp: GruSlot): the lane's four rows of one unit are one 16-byte store, a
         // wave's store instruction one contiguous KB.  Uniform 64-bit base (scalar registers) + 32-bit lane offset: no
@@ -378,15 +379,14 @@ struct GruWave {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            const float hn = accn[r] + accm[r];
-            const float ng = tanh_fast(acci[r] + rg[r] * hn);
+            const float hn = accn[r] + accm[r];                                   // 2^k (W_hn h + b_hn)
+            const float ng = 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2(esn * (acci[r] + rg[r] * hn)));   // tanh of 2^-k (...)
             const float hnew = ng + zg[r] * (hh[nxt][r] - ng);
-            unsigned u0, u1, u2;
-            split3(hnew, u0, u1, u2);
-            L.hb[0][nxt][i * HLD + j] = (unsigned short)(u0 >> 16);
-            L.hb[1][nxt][i * HLD + j] = (unsigned short)(u1 >> 16);
-            L.hb[2][nxt][i * HLD + j] = (unsigned short)(u2 >> 16);
-            if (SAVE) { svn[r] = ng; svhn[r] = hn; svh[r] = hnew; }
+            unsigned short u0, u1;
+            split2h(hnew * (float)(1 << F16_TOP), u0, u1);
+            L.hb[0][nxt][i * HLD + j] = u0;
+            L.hb[1][nxt][i * HLD + j] = u1;
+            if (SAVE) { svn[r] = ng; svhn[r] = hn * invn; svh[r] = hnew; }
             hh[cur][r] = hnew;
         }
         if (SAVE) {

@@ -43,7 +43,9 @@ struct GruFwdArgs {
 int launch_gru_fwd(const GruFwdArgs& args, bool save, hipStream_t st);
 // W_hh [192][64] fp32 -> three bf16 planes (hi, mid, lo; hi + mid + lo == w exactly) laid out as the
 // recurrence kernels load them: u32x4 [wave 4][gate 3][K chunk 2][plane 3][lane 64]
-constexpr int64_t GRU_PREP_BYTES = 4 * 3 * 2 * 3 * 64 * 16;
+constexpr int64_t GRU_PREP_BYTES = 4 * 3 * 2 * 3 * 64 * 16;     // per slot; the backward (three bf16 planes) fills it
+constexpr int64_t GRU_FWD_FRAG_BYTES = 4 * 3 * 2 * 2 * 64 * 16; // forward: two fp16 planes, then int32 k[192] (prepare_core.hpp)
+static_assert(GRU_FWD_FRAG_BYTES + 192 * 4 <= GRU_PREP_BYTES, "forward GRU fragments + row exponents fit the slot");
 int launch_gru_prepare(const float* const whh[3], int n, void* prep, hipStream_t st);
 
 // ---------------- Conv-attention encoder (dqn_per.py:21-55) ----------------

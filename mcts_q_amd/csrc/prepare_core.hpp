@@ -8,16 +8,30 @@
 
 namespace mctsq {
 
-// W_hh [192][64] of one GRU slot for the forward recurrence: [wave 4][gate 3][K chunk 2][plane 3][lane 64];
-// 1536 threads per slot
+// W_hh [192][64] of one GRU slot for the forward recurrence, as split-fp16 fragments (device_utils.hpp): every row
+// (output unit) is scaled by its own power of two 2^sh so that its largest magnitude lands in [2^14, 2^15):
+// [wave 4][gate 3][K chunk 2][plane 2][lane 64] u32x4, then int32 k[192] = 14 + sh per row (the exponent the
+// accumulators of that unit are scaled by: h goes in scaled by 2^14).  1536 threads per slot
 __device__ __forceinline__ void prep_gru_fwd(const float* __restrict__ whh, u32x4* __restrict__ out, int t) {
     const int lane = t & 63, c = (t >> 6) & 1, rest = t >> 7, g = rest % 3, wq = (rest / 3) & 3;
     const int jl = lane & 15, q = lane >> 4;
-    const float4* pw = reinterpret_cast<const float4*>(whh + (int64_t)(g * E + 16 * wq + jl) * E + 32 * c + 8 * q);
-    u32x4 hi, mid, lo;
-    split8(pw[0], pw[1], hi, mid, lo);
-    u32x4* o = out + (((wq * 3 + g) * 2 + c) * 3) * 64 + lane;
-    o[0] = hi; o[64] = mid; o[128] = lo;
+    const int row = g * E + 16 * wq + jl;
+    const float4* pr = reinterpret_cast<const float4*>(whh + (int64_t)row * E);
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < E / 4; ++i) {
+        const float4 v = pr[i];
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    const int sh = f16_row_shift(amax);
+    const float sc = pow2i(sh);
+    float4 a = pr[8 * c + 2 * q], b = pr[8 * c + 2 * q + 1];
+    a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc; b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
+    u32x4 hi, lo;
+    split8h(a, b, hi, lo);
+    u32x4* o = out + (((wq * 3 + g) * 2 + c) * 2) * 64 + lane;
+    o[0] = hi; o[64] = lo;
+    if (c == 0 && q == 0) reinterpret_cast<int*>(out + GRU_FWD_FRAG_BYTES / 16)[row] = F16_TOP + sh;
 }
 
 // W_hh of one GRU slot as the B operand of the BPTT product delta . W_hh: [wave 4][K chunk 6][plane 3][lane 64];

@@ -33,11 +33,12 @@ class DeviceQNet:
                                                                device=self.device)
         assert self.flat.numel() == self.n_flat and self.flat.is_contiguous()
         self._ws = None
-        # recurrent GRU weights split into bf16 planes (mctsq_q_prepare); rebuilt whenever the flat buffer
+        # weights as the matrix kernels read them (mctsq_q_prepare: split fragments; the GRU slots leave the tail of their
+        # region unwritten, hence zeros, so two prepared buffers of equal parameters compare equal); rebuilt whenever the flat buffer
         # changed: torch's version counter sees in-place torch ops (also through views()), the library's own
         # kernels (Adam, Polyak) do not, so their callers use mark_dirty()
         nprep = lib.check(lib.mctsq_q_prepared_bytes(C.byref(self.desc)))
-        self._prep = torch.empty(max(nprep, 16), dtype=torch.uint8, device=self.device)
+        self._prep = torch.zeros(max(nprep, 16), dtype=torch.uint8, device=self.device)
         self._prep_version = None
 
     def mark_dirty(self):

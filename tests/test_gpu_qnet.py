@@ -152,6 +152,50 @@ def test_gru_sharp_attention_uses_running_max(B):
     assert np.abs(q - ref64).max() <= 1e-5 * np.abs(ref64).max()
 
 
+@pytest.mark.parametrize("case", ["rows", "outliers", "tiny", "huge", "zero_rows"])
+def test_gru_recurrent_weights_of_any_scale(case):
+    """The recurrent product runs on the fp16 matrix instruction over a two-way split, with every row of W_hh scaled
+    by its own power of two into the fp16 range (prepare_core.hpp: prep_gru_fwd).  fp16 has 5 exponent bits, so the
+    scaling is what keeps the fp32 accuracy: rows 2^-30 .. 2^2 apart in magnitude, single outliers 2000 times the
+    rest of their row, an all-tiny and an all-large matrix (gates near saturation), and all-zero rows must stay
+    inside the 1e-5 bar against the fp64 oracle (the cases are kept where torch's fp32 path itself stays inside it:
+    with recurrent weights in the hundreds the recurrence is chaotic and fp32 evaluations differ by more)."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, "qnet_gru_gru_gru_per_relu.npz"))
+    sd = {k: v.copy() for k, v in sd.items()}
+    rng = np.random.RandomState(5)
+    keys = [k for k in sd if k.endswith("gru.weight_hh_l0")]
+    assert len(keys) == 3
+    for k in keys:
+        w = sd[k]                                            # [192, 64]
+        if case == "rows":
+            w *= (2.0 ** rng.randint(-30, 3, size=(192, 1))).astype(np.float32)
+        elif case == "outliers":
+            w *= np.float32(1e-3)
+            w[np.arange(192), rng.randint(0, 64, 192)] *= 2e3
+        elif case == "tiny":
+            w *= np.float32(1e-12)
+        elif case == "huge":
+            w *= np.float32(8.0)
+        else:
+            w[rng.rand(192) < 0.3] = 0.0
+    B = 50
+    g = torch.Generator().manual_seed(9)
+    price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
+        torch.rand(B, 3, 2, generator=g)
+    ref64 = qnet_numpy.q_forward(sd, cfg, price.numpy(), process.numpy(), gas.numpy(), np.float64)
+    with torch.no_grad():
+        ref32 = torch_ref.RefQNet.from_state_dict(cfg, sd)(price, process, gas).numpy()
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    q = net(price.cuda(), process.cuda(), gas.cuda())["q"].cpu().numpy()
+    scale = np.abs(ref64).max()
+    err_hip, err_cpu = np.abs(q - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+    print(f"{case}: HIP vs fp64 {err_hip:.2e}; torch-CPU vs fp64 {err_cpu:.2e}")
+    assert np.isfinite(q).all()
+    assert err_hip <= 1e-5
+
+
 @pytest.mark.parametrize("name", ["gru_gru_gru_per_relu", "conv_conv_mlp_per_relu", "transformer_transformer_gru_per_relu",
                                   "conv_gru_mlp_per_relu"])
 def test_self_preparing_entry_point_equals_prepared_one(name):
