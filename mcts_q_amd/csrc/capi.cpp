@@ -125,7 +125,10 @@ int prepare_impl(const NetLayout& L, const float* params, void* prep, hipStream_
         if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
         for (int l = 0; l < 2; ++l) {
             const TfLayerOff& o = L.enc[s].tfm.layer[l];
-            if (launch_tf_prepare(params + o.l1w, params + o.l2w, params + o.inw, params + o.ow, p, st)) return -1;
+            TfLayerW w{};
+            w.inw = params + o.inw; w.ow = params + o.ow; w.l1w = params + o.l1w; w.l1b = params + o.l1b;
+            w.l2w = params + o.l2w; w.n1w = params + o.n1w; w.n1b = params + o.n1b;
+            if (launch_tf_prepare(w, p, st)) return -1;
             p += TF_LAYER_PREP_BYTES;
         }
     }
@@ -658,9 +661,8 @@ int mctsq_encoder_forward(const mctsq_encoder_desc* enc, const float* d_enc_para
         TfArgs t;
         fill_tf_args(t, e, params, d_x, 0, B, Bp, feats, hbuf, nullptr);
         for (int l = 0; l < 2; ++l) {
-            const TfLayerOff& o = e.tfm.layer[l];
             char* p = prep + l * TF_LAYER_PREP_BYTES;
-            if (launch_tf_prepare(params + o.l1w, params + o.l2w, params + o.inw, params + o.ow, p, st)) return -1;
+            if (launch_tf_prepare(t.layer[l], p, st)) return -1;
             t.ffn_prep[l] = p;
         }
         if (launch_tf_fwd(t, st)) return -1;

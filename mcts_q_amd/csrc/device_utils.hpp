@@ -78,15 +78,18 @@ __device__ __forceinline__ void split2h(float xs, unsigned short& hi, unsigned s
     hi = __builtin_bit_cast(unsigned short, h);
     lo = __builtin_bit_cast(unsigned short, (_Float16)(xs - (float)h));
 }
-// 8 consecutive (already scaled) fp32 -> two packed fp16x8 planes (element e in bits 16(e&1) of word e>>1)
+// 8 consecutive (already scaled) fp32 -> two packed fp16x8 planes (element e in bits 16(e&1) of word e>>1).  Written
+// on two-element fp16 vectors so that the compiler converts straight into the halves of the packed word
+// (v_fma_mixlo / v_fma_mixhi_f16, with the caller's scale folded in) instead of assembling it with shifts.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8h(const float4& x0, const float4& x1, u32x4& hi, u32x4& lo) {
     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        unsigned short h0, l0, h1, l1;
-        split2h(x[2 * p], h0, l0);
-        split2h(x[2 * p + 1], h1, l1);
-        hi[p] = (unsigned)h0 | ((unsigned)h1 << 16); lo[p] = (unsigned)l0 | ((unsigned)l1 << 16);
+        f16x2 h, l;
+        h.x = (_Float16)x[2 * p]; h.y = (_Float16)x[2 * p + 1];
+        l.x = (_Float16)(x[2 * p] - (float)h.x); l.y = (_Float16)(x[2 * p + 1] - (float)h.y);
+        hi[p] = __builtin_bit_cast(unsigned, h); lo[p] = __builtin_bit_cast(unsigned, l);
     }
 }
 // power of two 2^e as a float, e in [-126, 127]

@@ -73,8 +73,33 @@ __device__ __forceinline__ void ln_rows(float x[4][4], const float* lnw, const f
     }
 }
 
-constexpr int FFN_FRAGS = 24, FFN_PAIRS = FF / 32;
-// six cross terms of the split product, smallest first
+// Prepared weights of one layer (kernels.hpp: TF_LAYER_PREP_BYTES): per pair of hidden tiles a region of FFN_REGION
+// u32x4, of which the FFN's split-fp16 fragments fill the first FFN_FRAGS * 64 of every pair laid out back to back
+// (64 x 16 KB), the scale tables (TfFfnTables) sit behind them at FFN_TABLES_OFF, and the attention block's split-bf16
+// fragments behind the whole FFN area.
+constexpr int FFN_FRAGS = 16, FFN_PAIRS = FF / 32, FFN_REGION = 24 * 64;
+constexpr int64_t FFN_TABLES_OFF = (int64_t)FFN_PAIRS * FFN_FRAGS * 64;       // u32x4 units
+static_assert((int64_t)FFN_PAIRS * FFN_REGION * 16 == TF_FFN_PREP_BYTES, "FFN area of the prepared buffer");
+// Scales of the split-fp16 FFN (device_utils.hpp: split2h).  Everything is a power of two:
+//   h (LayerNorm1 output, |h| <= hb = max_j 8 |n1w_j| + |n1b_j|) goes in as 2^kh h;
+//   row u of linear1 as 2^s1[u] W1[u][:]  -> its accumulator holds 2^(kh + s1[u]) (W1 h + b1)[u]  (b1s = scaled bias);
+//   after the ReLU rs[u] = 2^(ku - kh - s1[u]) brings every unit to the common scale 2^ku, chosen from the bound
+//   max_u |b1_u| + hb sum_k |W1[u][k]| so that 2^ku u stays inside the fp16 range;
+//   row n of linear2 as 2^s2[n] W2[n][:]  -> the output accumulator of feature n holds 2^(ku + s2[n]) times the sum;
+//   inv2[n] undoes it in the epilogue.
+struct TfFfnTables {
+    float b1s[FF], rs[FF], inv2[E];
+    int s1[FF], s2[E];
+    int kh, ku, pad_[2];
+};
+static_assert(FFN_TABLES_OFF * 16 + (int64_t)sizeof(TfFfnTables) <= TF_FFN_PREP_BYTES, "scale tables fit behind the fragments");
+// ReLU as ONE integer maximum: a float with the sign bit set is a negative integer (fmaxf costs a second
+// instruction that quiets signalling NaNs first)
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// three cross terms of the split-fp16 product, smallest first
+#define TF_MM3(ACC, XH, XL, YH, YL) \
+    ACC = mfma_h(XL, YH, ACC); ACC = mfma_h(XH, YL, ACC); ACC = mfma_h(XH, YH, ACC);
+// six cross terms of the split-bf16 product, smallest first
 #define TF_MM6(ACC, XH, XM, XL, YH, YM, YL)                                              \
     ACC = mfma_bf(XL, YH, ACC); ACC = mfma_bf(XH, YL, ACC); ACC = mfma_bf(XM, YM, ACC);   \
     ACC = mfma_bf(XM, YH, ACC); ACC = mfma_bf(XH, YM, ACC); ACC = mfma_bf(XH, YH, ACC);
@@ -102,7 +127,7 @@ __global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
 
     // ---- in_proj: [64 x 64] . W_in^T [64 x 192]; wave w owns row tile w.  Split-bf16 product (six cross
     // terms, fp32 accumulate) from prepared weight fragments; the 16 h rows are split here, once per wave.
-    const u32x4* aprep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]) + (int64_t)FFN_PAIRS * (FFN_FRAGS * 64) + lane;
+    const u32x4* aprep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]) + (int64_t)FFN_PAIRS * FFN_REGION + lane;
     {
         u32x4 xh[2], xm[2], xl[2];
         {
@@ -257,23 +282,25 @@ __global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
 
 // ------------------------------------------------------------------------------------ FFN block
 // hout = LayerNorm2(hin + W2 relu(W1 hin + b1) + b2).  One workgroup = 256 tokens, one wave = NT tiles of 16
-// tokens (NT = 1: 16 waves, four per SIMD, so one wave's split / ReLU VALU work overlaps its neighbours' matrix
-// work).  The 2048 hidden units are walked 32 at a time ("pair" of 16-unit tiles); the hidden tile never
+// tokens (NT = 2: 8 waves, two per SIMD, so one wave's split / ReLU VALU work overlaps its neighbour's matrix
+// work, and every weight fragment a wave reads from LDS serves two token tiles: at NT = 1 the 16 waves' fragment
+// reads, 256 KB per pair and CU, took more LDS cycles than the matrix instructions took issue cycles).  The 2048 hidden units are walked 32 at a time ("pair" of 16-unit tiles); the hidden tile never
 // leaves registers: the D layout of the first product (u^T = W1 . h^T: rows = hidden units, columns =
 // tokens) is exactly the A operand the second product (out = u . W2^T) wants, with the k slots of the
 // 16x16x32 instruction assigned to the units a lane already holds (slot e of lane group q: unit 4q+e of the
 // first tile for e < 4, unit 16+4q+e-4 of the second) -- the prepared W2 fragments use the same order.
-// Both products run on the bf16 matrix instruction over the exact three-way split of their operands
-// (six cross terms, fp32 accumulate: DESIGN.md section 3): h is split once per wave, the weights once per
-// parameter change (tf_prepare_kernel), u after the ReLU.  The pair's 24 weight fragments (24 KB) are
-// fetched once per workgroup into double-buffered LDS and shared by its four waves.
+// Both products run on the fp16 matrix instruction over the two-way split of their operands (three cross
+// terms, fp32 accumulate; power-of-two scales from TfFfnTables: DESIGN.md section 3): h is split once per wave,
+// the weights once per parameter change (tf_prepare_kernel), u after the ReLU.  The pair's 16 weight fragments
+// (16 KB) are fetched once per workgroup into double-buffered LDS and shared by its waves.
 #ifndef MCTSQ_FFN_NT
-#define MCTSQ_FFN_NT 1      // token tiles of 16 per wave: 1 -> 16 waves (four per SIMD) per 256-token workgroup; measured 4.01 ms (1), 4.12 (2), 4.73 (4) per 16384-leaf forward
+#define MCTSQ_FFN_NT 2      // token tiles of 16 per wave; measured per 16384-leaf forward: 2.55 ms (1), 2.41 (2), 2.98 (4); 3.07 for
+                            // (2) squeezed into 128 registers so that two workgroups share a CU
 #endif
 
 template <int NT>
 __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int layer) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];        // 48 KB
+    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];        // 32 KB
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
     const float* hin = Bf.hmid;
@@ -282,15 +309,21 @@ __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int la
     constexpr int NW = 16 / NT, NTHR = 64 * NW, NSTG = (FFN_FRAGS * 64 + NTHR - 1) / NTHR;   // waves, threads, staged b128 per thread
     const int64_t tok0 = (int64_t)blockIdx.x * TOK_PER_WG + w * (16 * NT);     // < Tp (grid = Tp / 256)
     const u32x4* prep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]);
-    // B operand of the first product: h^T, lane (token jl, k group q) holds h[token][32c + 8q .. +7], split
-    u32x4 hh[NT][2], hm[NT][2], hl[NT][2];
+    const TfFfnTables& tb = *reinterpret_cast<const TfFfnTables*>(prep + FFN_TABLES_OFF);
+    // B operand of the first product: 2^kh h^T, lane (token jl, k group q) holds h[token][32c + 8q .. +7], split
+    u32x4 hh[NT][2], hl[NT][2];
+    {
+        const float sh = pow2i(tb.kh);
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt)
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + 16 * tt + jl) * E + 32 * c + 8 * q);
-            split8(p[0], p[1], hh[tt][c], hm[tt][c], hl[tt][c]);
-        }
+            for (int c = 0; c < 2; ++c) {
+                const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + 16 * tt + jl) * E + 32 * c + 8 * q);
+                float4 x0 = p[0], x1 = p[1];
+                x0.x *= sh; x0.y *= sh; x0.z *= sh; x0.w *= sh; x1.x *= sh; x1.y *= sh; x1.z *= sh; x1.w *= sh;
+                split8h(x0, x1, hh[tt][c], hl[tt][c]);
+            }
+    }
     f32x4 acc[NT][4];
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
@@ -304,44 +337,58 @@ __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int la
 #pragma unroll
     for (int i = 0; i < NSTG; ++i)
         if (tid + NTHR * i < FFN_FRAGS * 64) wl[0][tid + NTHR * i] = stg[i];
-    const float* b1p = W.l1b + 4 * q;
+    // scaled bias and post-ReLU rescale of hidden units 4q + r (first tile) and 16 + 4q + r (second tile) of the pair
+    const float* b1p = tb.b1s + 4 * q;
+    const float* rsp = tb.rs + 4 * q;
     float4 b1n0 = *reinterpret_cast<const float4*>(b1p), b1n1 = *reinterpret_cast<const float4*>(b1p + 16);
+    float4 rsn0 = *reinterpret_cast<const float4*>(rsp), rsn1 = *reinterpret_cast<const float4*>(rsp + 16);
     __syncthreads();
+#pragma unroll 2
     for (int pr = 0; pr < FFN_PAIRS; ++pr) {
         const int buf = pr & 1;
-        const float4 b10 = b1n0, b11 = b1n1;
-        if (pr + 1 < FFN_PAIRS) {                                   // next pair's fragments and biases in flight
+        const float4 b10 = b1n0, b11 = b1n1, rs0 = rsn0, rs1 = rsn1;
+        if (pr + 1 < FFN_PAIRS) {                                   // next pair's fragments, biases and scales in flight
 #pragma unroll
             for (int i = 0; i < NSTG; ++i)
                 if (tid + NTHR * i < FFN_FRAGS * 64) stg[i] = prep[(int64_t)(pr + 1) * (FFN_FRAGS * 64) + tid + NTHR * i];
             b1n0 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32);
             b1n1 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32 + 16);
+            rsn0 = *reinterpret_cast<const float4*>(rsp + (pr + 1) * 32);
+            rsn1 = *reinterpret_cast<const float4*>(rsp + (pr + 1) * 32 + 16);
         }
         const u32x4* wf = &wl[buf][lane];
+        // every weight fragment is read from LDS once per wave and pair and serves all NT token tiles
+        // ---- u^T = W1 . h^T for the pair's two unit tiles, on top of the (scaled) bias of hidden unit 4q + r ----
+        f32x4 ua[NT], ub[NT];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            // ---- u^T = W1 . h^T for the pair's two unit tiles (bias of hidden unit 4q + r preloaded) ----
-            f32x4 ua = {b10.x, b10.y, b10.z, b10.w}, ub = {b11.x, b11.y, b11.z, b11.w};
+            ua[tt] = (f32x4){b10.x, b10.y, b10.z, b10.w};
+            ub[tt] = (f32x4){b11.x, b11.y, b11.z, b11.w};
+        }
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const u32x4 ah = wf[((0 * 2 + c) * 3 + 0) * 64], am = wf[((0 * 2 + c) * 3 + 1) * 64], al = wf[((0 * 2 + c) * 3 + 2) * 64];
-                const u32x4 bh = wf[((1 * 2 + c) * 3 + 0) * 64], bm = wf[((1 * 2 + c) * 3 + 1) * 64], bl = wf[((1 * 2 + c) * 3 + 2) * 64];
-                TF_MM6(ua, ah, am, al, hh[tt][c], hm[tt][c], hl[tt][c])
-                TF_MM6(ub, bh, bm, bl, hh[tt][c], hm[tt][c], hl[tt][c])
-            }
-            // ---- ReLU, split: the lane's 8 values are k slots 0..7 of the second product ----
-            u32x4 uh, um, ul;
-            {
-                const float4 v0 = make_float4(fmaxf(ua[0], 0.0f), fmaxf(ua[1], 0.0f), fmaxf(ua[2], 0.0f), fmaxf(ua[3], 0.0f));
-                const float4 v1 = make_float4(fmaxf(ub[0], 0.0f), fmaxf(ub[1], 0.0f), fmaxf(ub[2], 0.0f), fmaxf(ub[3], 0.0f));
-                split8(v0, v1, uh, um, ul);
-            }
-            // ---- out += u . W2^T ----
+        for (int c = 0; c < 2; ++c) {
+            const u32x4 ah = wf[((0 * 2 + c) * 2 + 0) * 64], al = wf[((0 * 2 + c) * 2 + 1) * 64];
+            const u32x4 bh = wf[((1 * 2 + c) * 2 + 0) * 64], bl = wf[((1 * 2 + c) * 2 + 1) * 64];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const u32x4 yh = wf[(12 + c * 3 + 0) * 64], ym = wf[(12 + c * 3 + 1) * 64], yl = wf[(12 + c * 3 + 2) * 64];
-                TF_MM6(acc[tt][c], uh, um, ul, yh, ym, yl)
+            for (int tt = 0; tt < NT; ++tt) {
+                TF_MM3(ua[tt], ah, al, hh[tt][c], hl[tt][c])
+                TF_MM3(ub[tt], bh, bl, hh[tt][c], hl[tt][c])
             }
+        }
+        // ---- ReLU, common scale 2^ku, split: the lane's 8 values are k slots 0..7 of the second product ----
+        u32x4 uh[NT], ul[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            const float4 v0 = make_float4(relu_bits(ua[tt][0]) * rs0.x, relu_bits(ua[tt][1]) * rs0.y, relu_bits(ua[tt][2]) * rs0.z, relu_bits(ua[tt][3]) * rs0.w);
+            const float4 v1 = make_float4(relu_bits(ub[tt][0]) * rs1.x, relu_bits(ub[tt][1]) * rs1.y, relu_bits(ub[tt][2]) * rs1.z, relu_bits(ub[tt][3]) * rs1.w);
+            split8h(v0, v1, uh[tt], ul[tt]);
+        }
+        // ---- out += u . W2^T ----
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4 yh = wf[(8 + c * 2 + 0) * 64], yl = wf[(8 + c * 2 + 1) * 64];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) { TF_MM3(acc[tt][c], uh[tt], ul[tt], yh, yl) }
         }
         if (pr + 1 < FFN_PAIRS) {
 #pragma unroll
@@ -351,16 +398,16 @@ __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int la
         __syncthreads();
     }
     if (tok0 >= a.T) return;
-    // ---- + b2 + residual, LayerNorm2 -------------------------------------------------------------
+    // ---- unscale, + b2 + residual, LayerNorm2 ----------------------------------------------------
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
         float x[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float bias = W.l2b[16 * c + jl];
+            const float bias = W.l2b[16 * c + jl], inv = tb.inv2[16 * c + jl];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                x[c][r] = (acc[tt][c][r] + bias) + hin[(tok0 + 16 * tt + 4 * q + r) * E + 16 * c + jl];
+                x[c][r] = (acc[tt][c][r] * inv + bias) + hin[(tok0 + 16 * tt + 4 * q + r) * E + 16 * c + jl];
         }
         {
             const int64_t t0 = tok0 + 16 * tt;
@@ -398,16 +445,76 @@ __global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) {
     a.feats[b * FEAT + a.out_col + lane] = v;
 }
 
-// FFN weights -> split-bf16 fragments: one thread per (pair, fragment group, lane); fragment order as
-// read by tf_ffn_kernel: W1 [unit tile m 2][K chunk c 2][plane 3], then W2 [out tile n 4][plane 3].
+// Scales of the split-fp16 FFN (TfFfnTables), one workgroup of 1024 threads per layer; runs ahead of tf_prepare_kernel.
+__device__ __forceinline__ float block_max_1024(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();                                          // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    return m;
+}
+__device__ __forceinline__ int clamp_exp(int e) { return e < -120 ? -120 : (e > 120 ? 120 : e); }
+__global__ __launch_bounds__(1024) void tf_scales_kernel(const float* __restrict__ l1w, const float* __restrict__ l1b,
+                                                         const float* __restrict__ l2w, const float* __restrict__ n1w,
+                                                         const float* __restrict__ n1b, TfFfnTables* __restrict__ tb) {
+    __shared__ float red[16];
+    const int t = threadIdx.x;
+    // |LayerNorm1 output| <= sqrt(E - 1) |n1w_j| + |n1b_j| < 8 |n1w_j| + |n1b_j|
+    const float hb = block_max_1024(t < E ? 8.0f * fabsf(n1w[t]) + fabsf(n1b[t]) : 0.0f, red);
+    const int kh = f16_row_shift(hb);
+    // rows of linear1 [2048][64]: 16 lanes per row (one 16-byte load each, a wave reads four whole rows per instruction)
+    float ubl = 0.0f;
+    const int part = t & 15;
+#pragma unroll 8
+    for (int it = 0; it < FF / 64; ++it) {
+        const int u = it * 64 + (t >> 4);
+        const float4 v = reinterpret_cast<const float4*>(l1w + (int64_t)u * E)[part];
+        const float amax = row16_max_dpp(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        const float asum = row16_sum((fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w)));
+        if (part == 0) tb->s1[u] = f16_row_shift(amax);
+        ubl = fmaxf(ubl, fabsf(l1b[u]) + asum * hb);
+    }
+    const float ub = block_max_1024(ubl, red);               // its barriers also publish s1[] to the workgroup
+    const int ku = f16_row_shift(ub);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = t + 1024 * i;
+        const int s1 = tb->s1[u];
+        tb->b1s[u] = l1b[u] * pow2i(clamp_exp(kh + s1));
+        tb->rs[u] = pow2i(clamp_exp(ku - kh - s1));
+    }
+    // rows of linear2 [64][2048]: 16 lanes per row, 32 loads of 16 bytes each with four independent maxima
+    {
+        const int n = t >> 4;
+        const float4* pr = reinterpret_cast<const float4*>(l2w + (int64_t)n * FF) + part;
+        float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < FF / 64; ++k) {
+            const float4 v = pr[k * 16];
+            m[k & 3] = fmaxf(m[k & 3], fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        const float amax = row16_max_dpp(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])));
+        if (part == 0) {
+            const int s2 = f16_row_shift(amax);
+            tb->s2[n] = s2;
+            tb->inv2[n] = pow2i(clamp_exp(-(ku + s2)));
+        }
+    }
+    if (t == 0) { tb->kh = kh; tb->ku = ku; }
+}
+
+// FFN weights -> split-fp16 fragments: one thread per (pair, fragment group, lane); fragment order as
+// read by tf_ffn_kernel: W1 [unit tile m 2][K chunk c 2][plane 2], then W2 [out tile n 4][plane 2]; rows scaled by
+// the powers of two tf_scales_kernel chose.  The attention block's projections stay split-bf16 (three planes).
 __global__ __launch_bounds__(256) void tf_prepare_kernel(const float* __restrict__ l1w, const float* __restrict__ l2w,
                                                         const float* __restrict__ inw, const float* __restrict__ ow,
                                                         u32x4* __restrict__ out) {
     const int gid = blockIdx.x * 256 + threadIdx.x;           // FFN_PAIRS * 8 * 64 threads, then 32 * 64 for the attention block
     const int lane = gid & 63, grp = (gid >> 6) & 7, pr = gid >> 9;
     const int jl = lane & 15, q = lane >> 4;
-    float4 v0, v1;
-    int f0;
     if (gid >= FFN_PAIRS * 8 * 64) {                          // in_proj / out_proj: (column tile, K chunk) per 64 lanes
         const int g2 = (gid - FFN_PAIRS * 8 * 64) >> 6;       // 0..23 in_proj, 24..31 out_proj
         const float* w = g2 < 24 ? inw : ow;
@@ -415,30 +522,39 @@ __global__ __launch_bounds__(256) void tf_prepare_kernel(const float* __restrict
         const float4* p = reinterpret_cast<const float4*>(w + (int64_t)(16 * tile + jl) * E + 32 * c + 8 * q);
         u32x4 hi, mid, lo;
         split8(p[0], p[1], hi, mid, lo);
-        u32x4* o = out + (int64_t)FFN_PAIRS * (FFN_FRAGS * 64) + lane;
+        u32x4* o = out + (int64_t)FFN_PAIRS * FFN_REGION + lane;
         o[(g2 * 3 + 0) * 64] = hi; o[(g2 * 3 + 1) * 64] = mid; o[(g2 * 3 + 2) * 64] = lo;
         return;
     }
+    const TfFfnTables& tb = *reinterpret_cast<const TfFfnTables*>(out + FFN_TABLES_OFF);
+    float4 v0, v1;
+    float sc;
+    int f0;
     if (grp < 4) {                                            // W1: unit tile m, K chunk c
-        const int m = grp >> 1, c = grp & 1;
-        const float4* p = reinterpret_cast<const float4*>(l1w + (int64_t)(32 * pr + 16 * m + jl) * E + 32 * c + 8 * q);
+        const int m = grp >> 1, c = grp & 1, u = 32 * pr + 16 * m + jl;
+        const float4* p = reinterpret_cast<const float4*>(l1w + (int64_t)u * E + 32 * c + 8 * q);
         v0 = p[0]; v1 = p[1];
-        f0 = (m * 2 + c) * 3;
+        sc = pow2i(tb.s1[u]);
+        f0 = (m * 2 + c) * 2;
     } else {                                                  // W2: output tile n; k slot e -> unit 4q+e | 16+4q+e-4
         const int n = grp - 4;
         const float* p = l2w + (int64_t)(16 * n + jl) * FF + 32 * pr + 4 * q;
         v0 = *reinterpret_cast<const float4*>(p); v1 = *reinterpret_cast<const float4*>(p + 16);
-        f0 = 12 + n * 3;
+        sc = pow2i(tb.s2[16 * n + jl]);
+        f0 = 8 + n * 2;
     }
-    u32x4 hi, mid, lo;
-    split8(v0, v1, hi, mid, lo);
+    v0.x *= sc; v0.y *= sc; v0.z *= sc; v0.w *= sc; v1.x *= sc; v1.y *= sc; v1.z *= sc; v1.w *= sc;
+    u32x4 hi, lo;
+    split8h(v0, v1, hi, lo);
     u32x4* o = out + (int64_t)pr * (FFN_FRAGS * 64) + lane;
-    o[(f0 + 0) * 64] = hi; o[(f0 + 1) * 64] = mid; o[(f0 + 2) * 64] = lo;
+    o[(f0 + 0) * 64] = hi; o[(f0 + 1) * 64] = lo;
 }
 
-int launch_tf_prepare(const float* l1w, const float* l2w, const float* inw, const float* ow, void* prep, hipStream_t st) {
-    hipLaunchKernelGGL(tf_prepare_kernel, dim3((FFN_PAIRS * 8 + 32) * 64 / 256), dim3(256), 0, st, l1w, l2w, inw, ow,
-                       reinterpret_cast<u32x4*>(prep));
+int launch_tf_prepare(const TfLayerW& w, void* prep, hipStream_t st) {
+    u32x4* out = reinterpret_cast<u32x4*>(prep);
+    hipLaunchKernelGGL(tf_scales_kernel, dim3(1), dim3(1024), 0, st, w.l1w, w.l1b, w.l2w, w.n1w, w.n1b,
+                       reinterpret_cast<TfFfnTables*>(out + FFN_TABLES_OFF));
+    hipLaunchKernelGGL(tf_prepare_kernel, dim3((FFN_PAIRS * 8 + 32) * 64 / 256), dim3(256), 0, st, w.l1w, w.l2w, w.inw, w.ow, out);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

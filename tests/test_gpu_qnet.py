@@ -196,6 +196,46 @@ def test_gru_recurrent_weights_of_any_scale(case):
     assert err_hip <= 1e-5
 
 
+@pytest.mark.parametrize("case", ["rows", "norm", "bias", "tiny"])
+def test_transformer_ffn_weights_of_any_scale(case):
+    """The feed-forward block runs on the fp16 matrix instruction over a two-way split; its power-of-two scales come
+    from the weights (enc_tf.hip: tf_scales_kernel -- rows of linear1 / linear2, the LayerNorm1 bound of the input,
+    the bound of the hidden units).  Rows of both matrices spread over 2^-20 .. 2^2, a LayerNorm1 with large scale and
+    shift, large hidden biases and an all-tiny block against the fp64 oracle."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, "qnet_transformer_transformer_gru_per_relu.npz"))
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    rng = np.random.RandomState(11)
+    n = 0
+    for k in sd:
+        if ".transformer.layers." not in k:
+            continue
+        if case == "rows" and k.endswith(("linear1.weight", "linear2.weight")):
+            sd[k] *= (2.0 ** rng.randint(-20, 3, size=(sd[k].shape[0], 1))).astype(np.float32); n += 1
+        elif case == "norm" and k.endswith(("norm1.weight", "norm1.bias")):
+            sd[k] = (sd[k] * 25.0 + 3.0).astype(np.float32); n += 1
+        elif case == "bias" and k.endswith("linear1.bias"):
+            sd[k] = (sd[k] * 200.0).astype(np.float32); n += 1
+        elif case == "tiny" and k.endswith(("linear1.weight", "linear1.bias", "linear2.weight")):
+            sd[k] *= np.float32(1e-9); n += 1
+    assert n >= 4
+    B = 37
+    g = torch.Generator().manual_seed(13)
+    price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
+        torch.rand(B, 3, 2, generator=g)
+    ref64 = qnet_numpy.q_forward(sd, cfg, price.numpy(), process.numpy(), gas.numpy(), np.float64)
+    with torch.no_grad():
+        ref32 = torch_ref.RefQNet.from_state_dict(cfg, sd)(price, process, gas).numpy()
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    q = net(price.cuda(), process.cuda(), gas.cuda())["q"].cpu().numpy()
+    scale = np.abs(ref64).max()
+    err_hip, err_cpu = np.abs(q - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+    print(f"{case}: HIP vs fp64 {err_hip:.2e}; torch-CPU vs fp64 {err_cpu:.2e}")
+    assert np.isfinite(q).all()
+    assert err_hip <= 1e-5
+
+
 @pytest.mark.parametrize("name", ["gru_gru_gru_per_relu", "conv_conv_mlp_per_relu", "transformer_transformer_gru_per_relu",
                                   "conv_gru_mlp_per_relu"])
 def test_self_preparing_entry_point_equals_prepared_one(name):
