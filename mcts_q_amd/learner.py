@@ -41,7 +41,7 @@ class DeviceLearner:
         self._small = torch.zeros(int(lib.mctsq_optim_workspace_bytes()), dtype=torch.uint8,
                                   device=self.device)                             # grad-norm partials
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
-        # weights as the kernels multiply by them (split bf16 fragments), refreshed once per parameter change by ONE
+        # weights as the kernels multiply by them (split 16-bit fragments), refreshed once per parameter change by ONE
         # launch: the policy's / target's forward fragments live in their DeviceQNet (leaf evaluation between steps
         # uses the policy's), the backward fragments here
         nb = lib.check(lib.mctsq_dqn_prepared_bwd_bytes(C.byref(self.desc)))
