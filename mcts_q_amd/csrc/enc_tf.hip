@@ -125,42 +125,56 @@ __global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
     const int rows = ns * S;
     const int64_t tok0 = sample0 * S;
 
-    // ---- in_proj: [64 x 64] . W_in^T [64 x 192]; wave w owns row tile w.  Split-bf16 product (six cross
-    // terms, fp32 accumulate) from prepared weight fragments; the 16 h rows are split here, once per wave.
+    // ---- in_proj: [64 x 64] . W_in^T [64 x 192].  Split-bf16 product (six cross terms, fp32 accumulate) from
+    // prepared weight fragments.  Wave w OWNS COLUMN TILES w, w + 4, w + 8 for all four row tiles, so it fetches a
+    // quarter of the weight fragments (18 of 72 KB: with a wave per row tile every wave pulled all 72 KB through
+    // the CU's vector memory path, 384 KB per workgroup of 64 tokens, which bounded the phase).  The 64 h rows are
+    // split once -- wave w its own row tile -- and exchanged as lane-major fragments through the (not yet used)
+    // q|k|v region of LDS; every wave then keeps all four row tiles' A fragments in registers.
     const u32x4* aprep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]) + (int64_t)FFN_PAIRS * FFN_REGION + lane;
     {
-        u32x4 xh[2], xm[2], xl[2];
+        u32x4* xa = reinterpret_cast<u32x4*>(qkv);                   // [row tile 4][chunk 2][plane 3][lane 64]: 24 KB
         {
             const bool ok = 16 * w + jl < rows;
             const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + (ok ? 16 * w + jl : 0)) * E + 8 * q);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const float4 z = make_float4(0, 0, 0, 0);
-                split8(ok ? p[8 * c] : z, ok ? p[8 * c + 1] : z, xh[c], xm[c], xl[c]);
+                u32x4 h3, m3, l3;
+                split8(ok ? p[8 * c] : z, ok ? p[8 * c + 1] : z, h3, m3, l3);
+                u32x4* dst = xa + ((w * 2 + c) * 3) * 64 + lane;
+                dst[0] = h3; dst[64] = m3; dst[128] = l3;
             }
         }
-        u32x4 wn[6];
+        __syncthreads();
+        u32x4 xf[4][2][3];
 #pragma unroll
-        for (int f = 0; f < 6; ++f) wn[f] = aprep[f * 64];
-        for (int nt = 0; nt < 12; ++nt) {
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xf[rt][c][pl] = xa[((rt * 2 + c) * 3 + pl) * 64 + lane];
+        __syncthreads();                                            // the fragments are in registers: q|k|v may be written
+#pragma unroll 1
+        for (int jt = 0; jt < 3; ++jt) {
+            const int nt = w + 4 * jt;
             u32x4 wc[6];
 #pragma unroll
-            for (int f = 0; f < 6; ++f) wc[f] = wn[f];
-            if (nt + 1 < 12) {                                      // next tile's weight fragments in flight
-#pragma unroll
-                for (int f = 0; f < 6; ++f) wn[f] = aprep[((nt + 1) * 6 + f) * 64];
-            }
-            f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            TF_MM6(acc0, xh[0], xm[0], xl[0], wc[0], wc[1], wc[2])
-            TF_MM6(acc1, xh[1], xm[1], xl[1], wc[3], wc[4], wc[5])
+            for (int f = 0; f < 6; ++f) wc[f] = aprep[(nt * 6 + f) * 64];
             const float bias = W.inb[16 * nt + jl];
             const float sc = nt < 4 ? 0.25f : 1.0f;                  // q / sqrt(head_dim)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v0 = ((acc0[r] + acc1[r]) + bias) * sc;
-                const int r0 = 16 * w + 4 * q + r;
-                qkv[r0 * QLD + 16 * nt + jl] = v0;
-                if (Bf.qkv && r0 < rows) Bf.qkv[(tok0 + r0) * G3 + 16 * nt + jl] = v0;
+            for (int rt = 0; rt < 4; ++rt) {
+                f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+                TF_MM6(acc0, xf[rt][0][0], xf[rt][0][1], xf[rt][0][2], wc[0], wc[1], wc[2])
+                TF_MM6(acc1, xf[rt][1][0], xf[rt][1][1], xf[rt][1][2], wc[3], wc[4], wc[5])
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = ((acc0[r] + acc1[r]) + bias) * sc;
+                    const int r0 = 16 * rt + 4 * q + r;
+                    qkv[r0 * QLD + 16 * nt + jl] = v0;
+                    if (Bf.qkv && r0 < rows) Bf.qkv[(tok0 + r0) * G3 + 16 * nt + jl] = v0;
+                }
             }
         }
     }
@@ -205,13 +219,13 @@ __global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = kt < nt16 ? expf(st[kt][r] - mx) : 0.0f;
+                    const float e = kt < nt16 ? fast_exp2((st[kt][r] - mx) * LOG2E) : 0.0f;   // v_exp_f32, ~1 ulp
                     st[kt][r] = e;
                     sum += e;
                 }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
+            const float inv = fast_rcp(sum);
             // ctx^T[d][query] = sum_key V[key][d] P[key][query]: A lane (d = jl, q) at step r holds V[16kt+4q+r][d]
             f32x4 ct = {0, 0, 0, 0};
 #pragma unroll

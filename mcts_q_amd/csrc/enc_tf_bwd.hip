@@ -283,11 +283,11 @@ __global__ __launch_bounds__(256) void tf_attn_bwd_kernel(TfBwdArgs a, int layer
             }
             float sum = 0.0f;
             for (int j = 0; j < S; ++j) {
-                const float e = expf(Pw[i * PLD + j] - mx);
+                const float e = fast_exp2((Pw[i * PLD + j] - mx) * LOG2E);      // as the forward evaluates it
                 Pw[i * PLD + j] = e;
                 sum += e;
             }
-            const float inv = 1.0f / sum;
+            const float inv = fast_rcp(sum);
             float Dd = 0.0f;
             for (int j = 0; j < S; ++j) {
                 const float* vj = &L.qkv[(rb + j) * BQLD + 2 * E + 16 * hh];
