@@ -3,8 +3,10 @@
 // One workgroup (4 waves) = one 16-sample tile of one conv slot.  Rows of every product are the 16
 // samples at ONE time step, so a k=3 convolution multiplies three consecutive rows [sample][channel] of
 // the previous layer (zero rows at t = -1 and t = S): conv2 is [16 x 192].[192 x 64] per step.  The forward
-// runs it on the bf16 matrix instruction (exact three-way split, prepared weight fragments resident in 72
-// VGPRs) and keeps only two h1 rows in LDS; the backward works on a full LDS image with fp32 MFMA.
+// runs it on the fp16 matrix instruction (two-way split, DESIGN.md section 3: prepared weight fragments with a
+// power-of-two scale per output channel resident in 48 VGPRs; the scale of the h1 rows follows from the
+// workgroup's largest input magnitude and the conv1 weights) and keeps only two h1 rows in LDS; the backward
+// works on a full LDS image with fp32 MFMA.
 // The softmax over time is folded online (one barrier per step), then LayerNorm.
 #include "kernels.hpp"
 #include "learner.hpp"
@@ -28,6 +30,7 @@ struct ConvFwdLds {
     float row[2][TILE * CLD];   // h1 rows in flight: row tp lives in slot tp & 1, written one step before it is read
     float xs[TILE * CXLD];
     PoolLds pool;
+    float bound[3][4];          // per wave: largest |x| staged, largest sum_k |w1_c[k]|, largest |b1_c| (the h1 bound below)
 };
 
 // Forward.  h1 never exists as a whole image: at step t every wave computes its 16 channels of row t+3 (conv1 is
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
     const int S = s.S, F = s.F, Fd = s.Fd, FP = F > 4 ? 8 : 4;
 
     // ---- stage the window (zero rows at both ends) ---------------------------------------------
+    float xmax = 0.0f;
     for (int idx = tid; idx < TILE * (S + 2) * FP; idx += 256) {
         const int i = idx / ((S + 2) * FP), rem = idx - i * ((S + 2) * FP), tp = rem / FP, f = rem - tp * FP;
         const int t = tp - 1;
@@ -53,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         if (t >= 0 && t < S && row0 + i < args.B && f < F)
             v = f < Fd ? s.x[(row0 + i) * (int64_t)(S * Fd) + t * Fd + f] : time_feature(s.tf, t, f - Fd);
         L.xs[i * XLD + rem] = v;
+        xmax = fmaxf(xmax, fabsf(v));
         if (SAVE) s.sv_x[((int64_t)tp * Bp + row0 + i) * 8 + f] = v;
     }
     if (SAVE && FP == 4)
@@ -74,19 +79,42 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         const int k = 4 * kk + q, tap = k / FP, f = k - tap * FP;
         w1f[kk] = (kk < nk1 && f < F) ? s.w1[(int64_t)j * F * 3 + f * 3 + tap] : 0.0f;
     }
-    // conv2 weights: prepared split-bf16 B fragments, chunk = 2 tap + half (32 input channels each)
-    u32x4 w2p[6][3];
+    // conv2 weights: prepared split-fp16 B fragments, chunk = 2 tap + half (32 input channels each), output channel j
+    // scaled by 2^s2[j] (conv_prepare_kernel; the exponents sit behind the fragments)
+    u32x4 w2p[6][2];
     {
-        const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep) + (int64_t)wq * (6 * 3 * 64) + lane;
+        const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep) + (int64_t)wq * (6 * 2 * 64) + lane;
 #pragma unroll
         for (int c = 0; c < 6; ++c)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) w2p[c][pl] = wp[(c * 3 + pl) * 64];
+            for (int pl = 0; pl < 2; ++pl) w2p[c][pl] = wp[(c * 2 + pl) * 64];
     }
+    const int s2j = reinterpret_cast<const int*>(reinterpret_cast<const char*>(s.wprep) + CONV_FRAG_BYTES)[j];
     const float b1j = s.b1[j], b2j = s.b2[j];
     PoolCore<SAVE> pc;
     pc.init(s.aw, s.ab, lane, wq);
+    // Bound of the h1 rows (the A operand of conv2): |h1_c| <= |b1_c| + xmax sum_k |w1_c[k]|, with xmax the largest
+    // input magnitude of THIS workgroup's windows (time features included).  Every lane folds its share, the waves
+    // exchange two numbers each, and all lanes derive the same power of two 2^kh for the rows.
+    {
+        float wsum = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) wsum += fabsf(w1f[kk]);
+        wsum += __shfl_xor(wsum, 16, 64);
+        wsum += __shfl_xor(wsum, 32, 64);                           // sum |w1_j[:]| of this lane's channel j
+        float xm = xmax, wm = wsum, bm = fabsf(b1j);
+        for (int o = 32; o > 0; o >>= 1) {
+            xm = fmaxf(xm, __shfl_xor(xm, o, 64)); wm = fmaxf(wm, __shfl_xor(wm, o, 64)); bm = fmaxf(bm, __shfl_xor(bm, o, 64));
+        }
+        if (lane == 0) { L.bound[0][wq] = xm; L.bound[1][wq] = wm; }
+        if (lane == 1) L.bound[2][wq] = bm;
+    }
     __syncthreads();
+    const float hbound = fmaxf(fmaxf(L.bound[2][0], L.bound[2][1]), fmaxf(L.bound[2][2], L.bound[2][3])) +
+                         fmaxf(fmaxf(L.bound[0][0], L.bound[0][1]), fmaxf(L.bound[0][2], L.bound[0][3])) *
+                             fmaxf(fmaxf(L.bound[1][0], L.bound[1][1]), fmaxf(L.bound[1][2], L.bound[1][3]));
+    const int kh = f16_row_shift(hbound);
+    const float sh = pow2i(kh), inv2 = pow2i(-(kh + s2j));          // row scale; un-scale of output channel j
 
     // conv1 + ReLU for image row tp (1..S = time step tp-1; S+1 = the zero pad) -> LDS slot tp & 1
     auto conv1_row = [&](int tp) {
@@ -106,17 +134,20 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         }
     };
     // ---- conv2 + ReLU, attention pooling folded online ---------------------------------------------
-    // [16 x 192] . [192 x 64] per step on the bf16 matrix instruction over the exact three-way split of both
-    // operands (six cross terms, fp32 accumulate: DESIGN.md section 3).
-    struct RowFrag { u32x4 h[2], m[2], l[2]; };
+    // [16 x 192] . [192 x 64] per step on the fp16 matrix instruction over the two-way split of both operands
+    // (three cross terms, fp32 accumulate: DESIGN.md section 3).
+    struct RowFrag { u32x4 h[2], l[2]; };
     auto load_row = [&](int tp, RowFrag& f) {
         const float4* p = reinterpret_cast<const float4*>(&L.row[tp & 1][(lane & 15) * CLD + 8 * q]);
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) split8(p[8 * hf], p[8 * hf + 1], f.h[hf], f.m[hf], f.l[hf]);
+        for (int hf = 0; hf < 2; ++hf) {
+            float4 a = p[8 * hf], b = p[8 * hf + 1];
+            a.x *= sh; a.y *= sh; a.z *= sh; a.w *= sh; b.x *= sh; b.y *= sh; b.z *= sh; b.w *= sh;
+            split8h(a, b, f.h[hf], f.l[hf]);
+        }
     };
 #define CONV_MM6(ACC, F, HF, W)                                                                           \
-    ACC = mfma_bf(F.l[HF], (W)[0], ACC); ACC = mfma_bf(F.h[HF], (W)[2], ACC); ACC = mfma_bf(F.m[HF], (W)[1], ACC); \
-    ACC = mfma_bf(F.m[HF], (W)[0], ACC); ACC = mfma_bf(F.h[HF], (W)[1], ACC); ACC = mfma_bf(F.h[HF], (W)[0], ACC);
+    ACC = mfma_h(F.l[HF], (W)[0], ACC); ACC = mfma_h(F.h[HF], (W)[1], ACC); ACC = mfma_h(F.h[HF], (W)[0], ACC);
     auto step = [&](int t, RowFrag& ra, RowFrag& rb, RowFrag& rc) {
         const int cur = t & 1, nxt = cur ^ 1;
         if (t + 3 <= S + 1) conv1_row(t + 3);                    // for the next step, into the other slot
@@ -128,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            v[r] = fmaxf(((acc0[r] + acc1[r]) + acc2[r]) + b2j, 0.0f);
+            v[r] = fmaxf(fmaf((acc0[r] + acc1[r]) + acc2[r], inv2, b2j), 0.0f);
             if (SAVE) s.sv_h2[((int64_t)t * Bp + row0 + 4 * q + r) * E + j] = v[r];
         }
         pc.publish(L.pool, nxt, v);
@@ -138,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         RowFrag f0, f1, f2;
         const u32x4 z = {0, 0, 0, 0};
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) { f0.h[hf] = z; f0.m[hf] = z; f0.l[hf] = z; }   // row 0: the zero pad at t = -1
+        for (int hf = 0; hf < 2; ++hf) { f0.h[hf] = z; f0.l[hf] = z; }   // row 0: the zero pad at t = -1
         conv1_row(1);
         __syncthreads();
         load_row(1, f1);
@@ -159,20 +190,33 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
     pc.fin2(L.pool, s.lnw, s.lnb, args.feats + row0 * FEAT + s.out_col, FEAT, s.sv_pool, s.sv_stat, row0);
 }
 
-// one thread per (slot, wave, chunk, lane): 8 input channels of one tap -> 3 x 8 bf16
+// one thread per (slot, wave, chunk, lane): 8 input channels of one tap -> 2 x 8 fp16, output channel (row of
+// conv2.weight [64][64][3]) scaled by its own power of two; the 64 exponents follow the fragments
 struct ConvPrepArgs { const float* w2[2]; u32x4* out; };
 __global__ __launch_bounds__(256) void conv_prepare_kernel(ConvPrepArgs a) {
     const int tid = blockIdx.x * 256 + threadIdx.x;           // grid = n * 6 blocks of 256
     const int lane = tid & 63, rest = tid >> 6, c = rest % 6, wq = (rest / 6) & 3, slot = rest / 24;
     const int jl = lane & 15, q = lane >> 4, tap = c >> 1, cin0 = 32 * (c & 1) + 8 * q;
-    const float* w = a.w2[slot] + (int64_t)(16 * wq + jl) * (E * 3) + tap;
+    const int ch = 16 * wq + jl;
+    const float4* row = reinterpret_cast<const float4*>(a.w2[slot] + (int64_t)ch * (E * 3));
+    float amax = 0.0f;
+#pragma unroll 8
+    for (int i = 0; i < E * 3 / 4; ++i) {
+        const float4 v = row[i];
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    const int sh = f16_row_shift(amax);
+    const float sc = pow2i(sh);
+    const float* w = a.w2[slot] + (int64_t)ch * (E * 3) + tap;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = w[(cin0 + e) * 3];
-    u32x4 hi, mid, lo;
-    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, mid, lo);
-    u32x4* o = a.out + (int64_t)slot * (CONV_PREP_BYTES / 16) + ((wq * 6 + c) * 3) * 64 + lane;
-    o[0] = hi; o[64] = mid; o[128] = lo;
+    for (int e = 0; e < 8; ++e) v[e] = w[(cin0 + e) * 3] * sc;
+    u32x4 hi, lo;
+    split8h(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+    u32x4* base = a.out + (int64_t)slot * (CONV_PREP_BYTES / 16);
+    u32x4* o = base + ((wq * 6 + c) * 2) * 64 + lane;
+    o[0] = hi; o[64] = lo;
+    if (c == 0 && q == 0) reinterpret_cast<int*>(base + CONV_FRAG_BYTES / 16)[ch] = sh;
 }
 int launch_conv_prepare(const float* const w2[2], int n, void* prep, hipStream_t st) {
     if (n == 0) return 0;

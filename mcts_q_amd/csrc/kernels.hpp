@@ -8,7 +8,7 @@ namespace mctsq {
 struct GruSlot {
     const float* x;                      // [B][S][Fd]
     const float *wih, *whh, *bih, *bhh, *aw, *ab, *lnw, *lnb;
-    const void* wprep;                   // W_hh split into bf16 planes in fragment order (gru_prepare_kernel)
+    const void* wprep;                   // W_hh as split-fp16 fragments + row exponents (gru_prepare_kernel)
     const void* wprep_t;                 // training: W_hh as B operand of delta . W_hh, split, lane-major (gru_prepare_bwd_kernel)
     int S, Fd, F, tf, out_col;
     // training-time activation record (NULL for inference), Bp = padded batch.  The per-step records are LANE-MAJOR:
@@ -52,7 +52,7 @@ int launch_gru_prepare(const float* const whh[3], int n, void* prep, hipStream_t
 struct ConvSlot {
     const float* x;                      // [B][S][Fd]
     const float *w1, *b1, *w2, *b2, *aw, *ab, *lnw, *lnb;
-    const void* wprep;                   // conv2 weights as split-bf16 fragments (conv_prepare_kernel)
+    const void* wprep;                   // conv2 weights as split-fp16 fragments + channel exponents (conv_prepare_kernel)
     int S, Fd, F, tf, out_col;
     // training record (NULL for inference)
     float* sv_h1;                        // [S+2][Bp][64] post-ReLU conv1, zero blocks at both ends
@@ -75,7 +75,9 @@ struct ConvFwdArgs {
 int launch_conv_fwd(const ConvFwdArgs& args, bool save, hipStream_t st);
 // conv2 weight [64 out][64 in][3 taps] fp32 -> three bf16 planes in the order the forward kernel loads them:
 // u32x4 [wave 4][K chunk 6 = 2 tap + half][plane 3][lane 64]; lane (jl, q) holds W2[16 wave + jl][32 half + 8q .. +7][tap]
-constexpr int64_t CONV_PREP_BYTES = 4 * 6 * 3 * 64 * 16;
+constexpr int64_t CONV_PREP_BYTES = 4 * 6 * 3 * 64 * 16;      // per slot (sized for three planes)
+constexpr int64_t CONV_FRAG_BYTES = 4 * 6 * 2 * 64 * 16;      // two fp16 planes, then int32 s2[64] (conv_prepare_kernel)
+static_assert(CONV_FRAG_BYTES + 64 * 4 <= CONV_PREP_BYTES, "conv fragments + channel exponents fit the slot");
 int launch_conv_prepare(const float* const w2[2], int n, void* prep, hipStream_t st);
 
 // ---------------- gas/EUA MLP encoder (dqn_per.py:108-114, 128-130) ----------------

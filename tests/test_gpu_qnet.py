@@ -196,6 +196,51 @@ def test_gru_recurrent_weights_of_any_scale(case):
     assert err_hip <= 1e-5
 
 
+@pytest.mark.parametrize("case", ["inputs_x1000", "inputs_tiny", "mixed_inputs", "w2_rows", "w1_large", "zero_inputs"])
+def test_conv_encoder_scales(case):
+    """The conv encoder's second convolution runs on the fp16 matrix instruction over a two-way split; the scale of
+    its A operand (the ReLU rows of conv1) is derived per workgroup from the largest input magnitude it staged and
+    from the conv1 weights, the scales of conv2's output channels from the prepared weights (enc_conv.hip).  Inputs
+    1000 times larger / 10^-6 times smaller than the usual [0, 1), leaves of very different magnitude inside one
+    16-leaf tile, conv2 rows spread over 2^-20 .. 2^3, large conv1 weights and all-zero windows against the fp64
+    oracle."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.qnet import DeviceQNet
+    z, cfg, sd = _load(os.path.join(GOLDEN, "qnet_conv_conv_mlp_per_relu.npz"))
+    sd = {k: np.array(v, copy=True) for k, v in sd.items()}
+    rng = np.random.RandomState(17)
+    B = 45
+    g = torch.Generator().manual_seed(19)
+    price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), \
+        torch.rand(B, 3, 2, generator=g)
+    n = 0
+    if case == "inputs_x1000":
+        price, process = price * 1000.0, process * 1000.0
+    elif case == "inputs_tiny":
+        price, process = price * 1e-6, process * 1e-6
+    elif case == "mixed_inputs":
+        f = torch.from_numpy((10.0 ** rng.randint(-4, 4, size=(B, 1, 1))).astype(np.float32))
+        price, process = price * f, process * f
+    elif case == "zero_inputs":
+        price, process = price * 0.0, process * 0.0
+    for k in sd:
+        if case == "w2_rows" and k.endswith("conv2.weight"):
+            sd[k] *= (2.0 ** rng.randint(-20, 4, size=(sd[k].shape[0], 1, 1))).astype(np.float32); n += 1
+        elif case == "w1_large" and k.endswith(("conv1.weight", "conv1.bias")):
+            sd[k] *= np.float32(50.0); n += 1
+    assert n >= 2 or case not in ("w2_rows", "w1_large")
+    ref64 = qnet_numpy.q_forward(sd, cfg, price.numpy(), process.numpy(), gas.numpy(), np.float64)
+    with torch.no_grad():
+        ref32 = torch_ref.RefQNet.from_state_dict(cfg, sd)(price, process, gas).numpy()
+    net = DeviceQNet(NetSpec.from_cfg(cfg)).load_state_dict(sd)
+    q = net(price.cuda(), process.cuda(), gas.cuda())["q"].cpu().numpy()
+    scale = np.abs(ref64).max()
+    err_hip, err_cpu = np.abs(q - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+    print(f"{case}: HIP vs fp64 {err_hip:.2e}; torch-CPU vs fp64 {err_cpu:.2e}")
+    assert np.isfinite(q).all()
+    assert err_hip <= 1e-5
+
+
 @pytest.mark.parametrize("case", ["rows", "norm", "bias", "tiny"])
 def test_transformer_ffn_weights_of_any_scale(case):
     """The feed-forward block runs on the fp16 matrix instruction over a two-way split; its power-of-two scales come
