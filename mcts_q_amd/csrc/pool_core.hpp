@@ -11,6 +11,7 @@ namespace mctsq {
 struct PoolLds {
     float spart[2][4][TILE];
     float red[2][4][TILE];
+    float dump[4][64 * 4];              // write-only sink of the non-publishing lanes (publish)
 };
 
 template <bool SAVE>
@@ -27,20 +28,26 @@ struct PoolCore {
     }
     // publish the score partials of the vector v (becomes h) into spart[buf]
     __device__ __forceinline__ void publish(PoolLds& L, int buf, const float v[4]) {
-        float ps[4];
+        float4 ps;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = v[r]; ps[r] = row16_sum(awj * v[r]); }
-        if (jl == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L.spart[buf][wq][4 * q + r] = ps[r];
-        }
+        for (int r = 0; r < 4; ++r) h[r] = v[r];
+        ps.x = row16_sum(awj * v[0]); ps.y = row16_sum(awj * v[1]); ps.z = row16_sum(awj * v[2]); ps.w = row16_sum(awj * v[3]);
+        // one lane per row group stores its four sums as 16 bytes; the others write theirs to a slot of their own:
+        // no branch around the store (gru_core.hpp: GruWave::publish)
+        float* dst = jl == 0 ? &L.spart[buf][wq][4 * q] : &L.dump[wq][(16 * q + jl) * 4];
+        *reinterpret_cast<float4*>(dst) = ps;
     }
     // fold h (whose score parts are in spart[buf]) into the running sums; call after a barrier
     __device__ __forceinline__ void attend(PoolLds& L, int buf, int t, float* sv_score, int64_t row0, int64_t Bp) {
+        float4 sp[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sp[w] = *reinterpret_cast<const float4*>(&L.spart[buf][w][4 * q]);
+        const float p[4][4] = {{sp[0].x, sp[0].y, sp[0].z, sp[0].w}, {sp[1].x, sp[1].y, sp[1].z, sp[1].w},
+                               {sp[2].x, sp[2].y, sp[2].z, sp[2].w}, {sp[3].x, sp[3].y, sp[3].z, sp[3].w}};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            const float sc = ((L.spart[buf][0][i] + L.spart[buf][1][i]) + (L.spart[buf][2][i] + L.spart[buf][3][i])) + ab;
+            const float sc = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) + ab;
             if (SAVE && wq == 0 && jl == 0) sv_score[(int64_t)t * Bp + row0 + i] = sc;
             const float d = sc - mrun[r];
             const float e = fast_exp2(-fabsf(d));
