@@ -86,9 +86,9 @@ int mctsq_q_forward_ex(const mctsq_net_desc* net, const float* d_params, const f
                        float* d_vmax, int32_t* d_argmax, float* d_prior, void* d_ws,
                        int64_t ws_bytes, void* stream, void* ev_encoders_done);
 
-/* ---- prepared weights.  The GRU recurrence (W_hh) and the transformer FFN multiply through the fp16
- * matrix instruction on a two-way split of every fp32 weight, rows scaled by powers of two into the fp16
- * range; the conv encoder's second convolution, the attention projections and the head of the fused
+/* ---- prepared weights.  The GRU recurrence (W_hh), the conv encoder's second convolution and the
+ * transformer FFN multiply through the fp16 matrix instruction on a two-way split of every fp32 weight,
+ * rows scaled by powers of two into the fp16 range; the attention projections and the head of the fused
  * gru/gru/gru kernel through the bf16 matrix instruction on an exact three-way split (DESIGN.md
  * section 3; both forms are fp32-accurate).  The buffer's contents are private to the library
  * version that wrote them.  mctsq_q_forward splits

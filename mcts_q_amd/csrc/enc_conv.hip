@@ -34,7 +34,7 @@ struct ConvFwdLds {
 };
 
 // Forward.  h1 never exists as a whole image: at step t every wave computes its 16 channels of row t+3 (conv1 is
-// 3-6 fp32 MFMAs) into a two-slot LDS buffer, reads row t+2 ONCE, splits it into bf16 planes in registers, and
+// 3-6 fp32 MFMAs) into a two-slot LDS buffer, reads row t+2 ONCE, splits it into two fp16 planes in registers, and
 // multiplies rows t, t+1, t+2 (taps 0, 1, 2 of conv2) from three rotating register sets.  25 KB of LDS and
 // ~200 VGPRs let two workgroups (e.g. the price and the process window of one tile) share a CU.
 template <bool SAVE>

@@ -41,8 +41,8 @@ struct GruFwdArgs {
     float* feats;                        // [Bp][192]
 };
 int launch_gru_fwd(const GruFwdArgs& args, bool save, hipStream_t st);
-// W_hh [192][64] fp32 -> three bf16 planes (hi, mid, lo; hi + mid + lo == w exactly) laid out as the
-// recurrence kernels load them: u32x4 [wave 4][gate 3][K chunk 2][plane 3][lane 64]
+// W_hh [192][64] fp32 -> split-fp16 fragments as the recurrence kernels load them (prepare_core.hpp: prep_gru_fwd):
+// u32x4 [wave 4][gate 3][K chunk 2][plane 2][lane 64], rows scaled by powers of two, then the 192 row exponents
 constexpr int64_t GRU_PREP_BYTES = 4 * 3 * 2 * 3 * 64 * 16;     // per slot; the backward (three bf16 planes) fills it
 constexpr int64_t GRU_FWD_FRAG_BYTES = 4 * 3 * 2 * 2 * 64 * 16; // forward: two fp16 planes, then int32 k[192] (prepare_core.hpp)
 static_assert(GRU_FWD_FRAG_BYTES + 192 * 4 <= GRU_PREP_BYTES, "forward GRU fragments + row exponents fit the slot");
@@ -73,8 +73,9 @@ struct ConvFwdArgs {
     float* feats;                        // [Bp][192]
 };
 int launch_conv_fwd(const ConvFwdArgs& args, bool save, hipStream_t st);
-// conv2 weight [64 out][64 in][3 taps] fp32 -> three bf16 planes in the order the forward kernel loads them:
-// u32x4 [wave 4][K chunk 6 = 2 tap + half][plane 3][lane 64]; lane (jl, q) holds W2[16 wave + jl][32 half + 8q .. +7][tap]
+// conv2 weight [64 out][64 in][3 taps] fp32 -> split-fp16 fragments in the order the forward kernel loads them:
+// u32x4 [wave 4][K chunk 6 = 2 tap + half][plane 2][lane 64]; lane (jl, q) holds W2[16 wave + jl][32 half + 8q .. +7][tap]
+// times the output channel's power of two; the 64 channel exponents follow
 constexpr int64_t CONV_PREP_BYTES = 4 * 6 * 3 * 64 * 16;      // per slot (sized for three planes)
 constexpr int64_t CONV_FRAG_BYTES = 4 * 6 * 2 * 64 * 16;      // two fp16 planes, then int32 s2[64] (conv_prepare_kernel)
 static_assert(CONV_FRAG_BYTES + 64 * 4 <= CONV_PREP_BYTES, "conv fragments + channel exponents fit the slot");

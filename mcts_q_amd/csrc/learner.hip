@@ -393,7 +393,8 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
 
     // W_hh as B operand of the delta . W_hh product (k = gate row, col = unit j): prepared split-bf16 fragments,
     // 6 K chunks x 3 planes resident in 72 VGPRs.  The product runs on the bf16 matrix instruction over the exact
-    // three-way split of both operands (six cross terms, fp32 accumulate), like the forward recurrence.
+    // three-way split of both operands (six cross terms, fp32 accumulate); the forward recurrence, whose operands have
+    // known bounds, uses the two-way fp16 split instead (the deltas here have none).
     u32x4 wt[6][3];
     {
         const u32x4* wp = reinterpret_cast<const u32x4*>(s.wprep_t) + (int64_t)wq * (6 * 3 * 64) + lane;

@@ -1,6 +1,7 @@
 // Weight preparation shared by the per-purpose prepare kernels and the learner's one-launch prepare
-// (dqn_prepare_kernel): fp32 weights -> three bf16 planes (hi + mid + lo == w exactly) laid out as the B-operand
-// fragments the consuming kernels load, u32x4 [fragment][lane 64].  `t` = thread index inside the job.
+// (dqn_prepare_kernel): fp32 weights -> 16-bit planes laid out as the B-operand fragments the consuming kernels
+// load, u32x4 [fragment][lane 64]: three bf16 planes (hi + mid + lo == w exactly) for the heads and the backward's
+// W_hh, two fp16 planes of power-of-two scaled rows for the forward recurrence (device_utils.hpp).  `t` = thread index inside the job.
 #pragma once
 #include "device_utils.hpp"
 #include "kernels.hpp"
