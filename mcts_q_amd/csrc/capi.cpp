@@ -233,14 +233,16 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
     {
         float* hbuf = ws + Bp * FEAT;
         const char* tprep = (const char*)prep + gru_prepared_bytes(L) + conv_prepared_bytes(L);
+        TfArgs t[2];
+        int nt = 0;
         for (int s = 0; s < 2; ++s) {
             if (L.enc[s].kind != MCTSQ_ENC_TRANSFORMER) continue;
-            TfArgs t;
-            fill_tf_args(t, L.enc[s], params, x[s], s, B, Bp, feats, hbuf, sv ? &sv[s] : nullptr);
-            for (int l = 0; l < 2; ++l) { t.ffn_prep[l] = tprep; tprep += TF_LAYER_PREP_BYTES; }
-            if (launch_tf_fwd(t, st)) return -1;
-            hbuf += 2 * t.Tp * E;
+            fill_tf_args(t[nt], L.enc[s], params, x[s], s, B, Bp, feats, hbuf, sv ? &sv[s] : nullptr);
+            for (int l = 0; l < 2; ++l) { t[nt].ffn_prep[l] = tprep; tprep += TF_LAYER_PREP_BYTES; }
+            hbuf += 2 * t[nt].Tp * E;
+            ++nt;
         }
+        if (nt == 2 ? launch_tf_fwd_pair(t[0], t[1], st) : (nt == 1 ? launch_tf_fwd(t[0], st) : 0)) return -1;
     }
     if (launch_conv_fwd(ca, save, st)) return -1;          // longest kernels first
     if (launch_gru_fwd(ga, save, st)) return -1;

@@ -313,15 +313,14 @@ __global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
 #endif
 
 template <int NT>
-__global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int layer) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];        // 32 KB
+__device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_FRAGS * 64], const TfArgs& a, int layer, int bid) {
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
     const float* hin = Bf.hmid;
     float* hout = Bf.hout;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
     constexpr int NW = 16 / NT, NTHR = 64 * NW, NSTG = (FFN_FRAGS * 64 + NTHR - 1) / NTHR;   // waves, threads, staged b128 per thread
-    const int64_t tok0 = (int64_t)blockIdx.x * TOK_PER_WG + w * (16 * NT);     // < Tp (grid = Tp / 256)
+    const int64_t tok0 = (int64_t)bid * TOK_PER_WG + w * (16 * NT);            // < Tp (Tp / 256 blocks per encoder)
     const u32x4* prep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]);
     const TfFfnTables& tb = *reinterpret_cast<const TfFfnTables*>(prep + FFN_TABLES_OFF);
     // B operand of the first product: 2^kh h^T, lane (token jl, k group q) holds h[token][32c + 8q .. +7], split
@@ -438,6 +437,21 @@ __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int la
             }
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int layer) {
+    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];        // 32 KB
+    tf_ffn_body<NT>(wl, a, layer, (int)blockIdx.x);
+}
+// The FFN blocks of TWO encoders (price and process window of one network) as one grid: launched one after the
+// other, each grid ends with a round in which most CUs idle (1600 and 640 workgroups on 256 CUs: 7 + 3 rounds);
+// together they take 9.
+template <int NT>
+__global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_pair_kernel(TfArgs a, TfArgs b, int na, int layer) {
+    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];
+    if ((int)blockIdx.x < na) tf_ffn_body<NT>(wl, a, layer, (int)blockIdx.x);
+    else tf_ffn_body<NT>(wl, b, layer, (int)blockIdx.x - na);
 }
 
 // ----------------------------------------------------------------- mean over time + LayerNorm
@@ -588,6 +602,34 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(tf_ffn_kernel<MCTSQ_FFN_NT>, dim3(ffn_grid), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st, a, l);
     }
     hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);
+    MCTSQ_HIP(hipGetLastError());
+    return 0;
+}
+
+static int tf_check(const TfArgs& a) {
+    MCTSQ_CHECK(a.S >= 1 && a.S <= 32, "transformer encoder: seq_len %d outside 1..32", a.S);
+    MCTSQ_CHECK(a.Tp % TOK_PER_WG == 0 && a.Tp >= a.T && a.T == a.B * a.S, "transformer encoder: bad token padding");
+    MCTSQ_CHECK(a.NS >= 1 && a.NS * a.S <= AROWS, "transformer encoder: samples per workgroup");
+    MCTSQ_CHECK(a.ffn_prep[0] && a.ffn_prep[1], "transformer encoder needs prepared FFN weights");
+    return 0;
+}
+
+// two transformer encoders of one network: same stages, the FFN of both as one grid per layer
+int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st) {
+    if (a.B == 0) return 0;
+    if (tf_check(a) || tf_check(b)) return -1;
+    MCTSQ_CHECK(a.B == b.B, "transformer encoder pair: batch mismatch");
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(b.Tp / 16)), dim3(256), 0, st, b);
+    const int na = (int)(a.Tp / TOK_PER_WG), nb = (int)(b.Tp / TOK_PER_WG);
+    for (int l = 0; l < 2; ++l) {
+        hipLaunchKernelGGL(tf_attn_kernel, dim3((unsigned)((a.B + a.NS - 1) / a.NS)), dim3(256), 0, st, a, l);
+        hipLaunchKernelGGL(tf_attn_kernel, dim3((unsigned)((b.B + b.NS - 1) / b.NS)), dim3(256), 0, st, b, l);
+        hipLaunchKernelGGL(tf_ffn_pair_kernel<MCTSQ_FFN_NT>, dim3((unsigned)(na + nb)), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st,
+                           a, b, na, l);
+    }
+    hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((b.Bp + 3) / 4)), dim3(256), 0, st, b);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -125,6 +125,7 @@ struct TfArgs {
 };
 int64_t tf_padded_tokens(int64_t B, int S);
 int launch_tf_fwd(const TfArgs& a, hipStream_t st);
+int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st);   // two encoders of one network, FFN grids merged
 // FFN weights of one layer (linear1 [2048][64], linear2 [64][2048]) -> split-fp16 fragments in the
 // order tf_ffn_kernel consumes them: u32x4 [pair of hidden tiles 64][fragment 16][lane 64] (1 MB), then the scale
 // tables of the split (enc_tf.hip: TfFfnTables) inside the same area
