@@ -112,15 +112,14 @@ __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(
 // straight from global memory.
 constexpr int QLD = 196, AROWS = 64;
 
-__global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
-    __shared__ __attribute__((aligned(16))) float qkv[AROWS * QLD];
+__device__ __forceinline__ void tf_attn_body(float (&qkv)[AROWS * QLD], const TfArgs& a, int layer, int bid) {
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
     const float* hin = Bf.hin;
     float* hout = Bf.hmid;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
     const int S = a.S, NS = a.NS;
-    const int64_t sample0 = (int64_t)blockIdx.x * NS;
+    const int64_t sample0 = (int64_t)bid * NS;
     const int ns = (int)min((int64_t)NS, a.B - sample0);
     const int rows = ns * S;
     const int64_t tok0 = sample0 * S;
@@ -292,6 +291,17 @@ __global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256, 3) void tf_attn_kernel(TfArgs a, int layer) {
+    __shared__ __attribute__((aligned(16))) float qkv[AROWS * QLD];
+    tf_attn_body(qkv, a, layer, (int)blockIdx.x);
+}
+// the attention blocks of two encoders of one network as one grid (as tf_ffn_pair_kernel below)
+__global__ __launch_bounds__(256, 3) void tf_attn_pair_kernel(TfArgs a, TfArgs b, int na, int layer) {
+    __shared__ __attribute__((aligned(16))) float qkv[AROWS * QLD];
+    if ((int)blockIdx.x < na) tf_attn_body(qkv, a, layer, (int)blockIdx.x);
+    else tf_attn_body(qkv, b, layer, (int)blockIdx.x - na);
 }
 
 // ------------------------------------------------------------------------------------ FFN block
@@ -623,8 +633,8 @@ int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st) {
     hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(b.Tp / 16)), dim3(256), 0, st, b);
     const int na = (int)(a.Tp / TOK_PER_WG), nb = (int)(b.Tp / TOK_PER_WG);
     for (int l = 0; l < 2; ++l) {
-        hipLaunchKernelGGL(tf_attn_kernel, dim3((unsigned)((a.B + a.NS - 1) / a.NS)), dim3(256), 0, st, a, l);
-        hipLaunchKernelGGL(tf_attn_kernel, dim3((unsigned)((b.B + b.NS - 1) / b.NS)), dim3(256), 0, st, b, l);
+        const int ga = (int)((a.B + a.NS - 1) / a.NS), gb = (int)((b.B + b.NS - 1) / b.NS);
+        hipLaunchKernelGGL(tf_attn_pair_kernel, dim3((unsigned)(ga + gb)), dim3(256), 0, st, a, b, ga, l);
         hipLaunchKernelGGL(tf_ffn_pair_kernel<MCTSQ_FFN_NT>, dim3((unsigned)(na + nb)), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st,
                            a, b, na, l);
     }
