@@ -92,8 +92,12 @@ __device__ __forceinline__ void split8h(const float4& x0, const float4& x1, u32x
         hi[p] = __builtin_bit_cast(unsigned, h); lo[p] = __builtin_bit_cast(unsigned, l);
     }
 }
-// power of two 2^e as a float, e in [-126, 127]
-__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+// power of two 2^e as a float; e is clamped to the normal range [-126, 127] (exponents outside it only arise from
+// weights or inputs beyond 2^+-100, where the fp32 evaluation overflows as well)
+__device__ __forceinline__ float pow2i(int e) {
+    e = e < -126 ? -126 : (e > 127 ? 127 : e);
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
 // the power-of-two exponent that brings a row of largest magnitude `amax` into [2^F16_TOP, 2^(F16_TOP+1))
 __device__ __forceinline__ int f16_row_shift(float amax) {
     const int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;      // floor(log2 amax) for normal amax
