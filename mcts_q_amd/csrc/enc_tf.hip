@@ -16,9 +16,9 @@ constexpr int TOK_PER_WG = 256;
 // -------------------------------------------------------------------------------- embedding
 // One workgroup = 16 tokens x 64 columns; a thread keeps its column of the embedding weights in registers and
 // walks 4 consecutive tokens (one division per thread, (sample, step) advanced incrementally).
-__global__ __launch_bounds__(256) void tf_embed_kernel(TfArgs a) {
+__device__ __forceinline__ void tf_embed_body(const TfArgs& a, int bid) {
     const int c = threadIdx.x & 63;
-    const int64_t tok0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 6) * 4;    // < Tp (grid = Tp / 16)
+    const int64_t tok0 = (int64_t)bid * 16 + (threadIdx.x >> 6) * 4;           // < Tp (Tp / 16 blocks per encoder)
     float w[MAX_F];
 #pragma unroll
     for (int f = 0; f < MAX_F; ++f) w[f] = f < a.F ? a.ew[c * a.F + f] : 0.0f;
@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256) void tf_embed_kernel(TfArgs a) {
         a.buf[0].hin[tok * E + c] = v;
         if (++t == a.S) { t = 0; ++b; }
     }
+}
+
+__global__ __launch_bounds__(256) void tf_embed_kernel(TfArgs a) { tf_embed_body(a, (int)blockIdx.x); }
+// two encoders of one network as one grid (as tf_ffn_pair_kernel)
+__global__ __launch_bounds__(256) void tf_embed_pair_kernel(TfArgs a, TfArgs b, int na) {
+    if ((int)blockIdx.x < na) tf_embed_body(a, (int)blockIdx.x);
+    else tf_embed_body(b, (int)blockIdx.x - na);
 }
 
 // LayerNorm over the 64 columns of rows held in the MFMA D layout: x[c][r] is column 16c + jl of
@@ -465,9 +472,9 @@ __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_pair_kernel(TfArgs a, T
 }
 
 // ----------------------------------------------------------------- mean over time + LayerNorm
-__global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) {
+__device__ __forceinline__ void tf_pool_body(const TfArgs& a, int bid) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)bid * 4 + (threadIdx.x >> 6);
     if (b >= a.Bp) return;
     float v = 0.0f;
     if (b < a.B) {
@@ -481,6 +488,11 @@ __global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) {
         if (a.sv_mean) a.sv_mean[b * E + lane] = m;
     }
     a.feats[b * FEAT + a.out_col + lane] = v;
+}
+__global__ __launch_bounds__(256) void tf_pool_kernel(TfArgs a) { tf_pool_body(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void tf_pool_pair_kernel(TfArgs a, TfArgs b, int na) {
+    if ((int)blockIdx.x < na) tf_pool_body(a, (int)blockIdx.x);
+    else tf_pool_body(b, (int)blockIdx.x - na);
 }
 
 // Scales of the split-fp16 FFN (TfFfnTables), one workgroup of 1024 threads per layer; runs ahead of tf_prepare_kernel.
@@ -629,8 +641,7 @@ int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st) {
     if (a.B == 0) return 0;
     if (tf_check(a) || tf_check(b)) return -1;
     MCTSQ_CHECK(a.B == b.B, "transformer encoder pair: batch mismatch");
-    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp / 16)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(b.Tp / 16)), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(tf_embed_pair_kernel, dim3((unsigned)(a.Tp / 16 + b.Tp / 16)), dim3(256), 0, st, a, b, (int)(a.Tp / 16));
     const int na = (int)(a.Tp / TOK_PER_WG), nb = (int)(b.Tp / TOK_PER_WG);
     for (int l = 0; l < 2; ++l) {
         const int ga = (int)((a.B + a.NS - 1) / a.NS), gb = (int)((b.B + b.NS - 1) / b.NS);
@@ -638,8 +649,8 @@ int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st) {
         hipLaunchKernelGGL(tf_ffn_pair_kernel<MCTSQ_FFN_NT>, dim3((unsigned)(na + nb)), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st,
                            a, b, na, l);
     }
-    hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((b.Bp + 3) / 4)), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(tf_pool_pair_kernel, dim3((unsigned)((a.Bp + 3) / 4 + (b.Bp + 3) / 4)), dim3(256), 0, st, a, b,
+                       (int)((a.Bp + 3) / 4));
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
