@@ -324,19 +324,26 @@ __global__ __launch_bounds__(256, 3) void tf_attn_pair_kernel(TfArgs a, TfArgs b
 // terms, fp32 accumulate; power-of-two scales from TfFfnTables: DESIGN.md section 3): h is split once per wave,
 // the weights once per parameter change (tf_prepare_kernel), u after the ReLU.  The pair's 16 weight fragments
 // (16 KB) are fetched once per workgroup into double-buffered LDS and shared by its waves.
+#ifndef MCTSQ_FFN_SP
+#define MCTSQ_FFN_SP 1      // pairs of hidden tiles staged per barrier; measured per 16384-leaf forward: 2.18 ms (1), 2.19 (2), 2.52 (4):
+                            // the barrier per pair is not what bounds the kernel
+#endif
+constexpr int FFN_SP = MCTSQ_FFN_SP;
+static_assert(FFN_PAIRS % FFN_SP == 0, "staged groups cover the hidden units");
 #ifndef MCTSQ_FFN_NT
 #define MCTSQ_FFN_NT 2      // token tiles of 16 per wave; measured per 16384-leaf forward: 2.55 ms (1), 2.41 (2), 2.98 (4); 3.07 for
                             // (2) squeezed into 128 registers so that two workgroups share a CU
 #endif
 
 template <int NT>
-__device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_FRAGS * 64], const TfArgs& a, int layer, int bid) {
+__device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_SP * FFN_FRAGS * 64], const TfArgs& a, int layer, int bid) {
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
     const float* hin = Bf.hmid;
     float* hout = Bf.hout;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
-    constexpr int NW = 16 / NT, NTHR = 64 * NW, NSTG = (FFN_FRAGS * 64 + NTHR - 1) / NTHR;   // waves, threads, staged b128 per thread
+    constexpr int SP = FFN_SP, GFR = SP * FFN_FRAGS * 64;       // pairs per staged group (one barrier per group), its b128 count
+    constexpr int NW = 16 / NT, NTHR = 64 * NW, NSTG = (GFR + NTHR - 1) / NTHR;   // waves, threads, staged b128 per thread
     const int64_t tok0 = (int64_t)bid * TOK_PER_WG + w * (16 * NT);            // < Tp (Tp / 256 blocks per encoder)
     const u32x4* prep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]);
     const TfFfnTables& tb = *reinterpret_cast<const TfFfnTables*>(prep + FFN_TABLES_OFF);
@@ -363,30 +370,41 @@ __device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_FRAGS * 64], cons
     u32x4 stg[NSTG];
 #pragma unroll
     for (int i = 0; i < NSTG; ++i)
-        if (tid + NTHR * i < FFN_FRAGS * 64) stg[i] = prep[tid + NTHR * i];
+        if (tid + NTHR * i < GFR) stg[i] = prep[tid + NTHR * i];
 #pragma unroll
     for (int i = 0; i < NSTG; ++i)
-        if (tid + NTHR * i < FFN_FRAGS * 64) wl[0][tid + NTHR * i] = stg[i];
-    // scaled bias and post-ReLU rescale of hidden units 4q + r (first tile) and 16 + 4q + r (second tile) of the pair
+        if (tid + NTHR * i < GFR) wl[0][tid + NTHR * i] = stg[i];
+    // scaled bias and post-ReLU rescale of hidden units 4q + r (first tile) and 16 + 4q + r (second tile) of a pair
     const float* b1p = tb.b1s + 4 * q;
     const float* rsp = tb.rs + 4 * q;
-    float4 b1n0 = *reinterpret_cast<const float4*>(b1p), b1n1 = *reinterpret_cast<const float4*>(b1p + 16);
-    float4 rsn0 = *reinterpret_cast<const float4*>(rsp), rsn1 = *reinterpret_cast<const float4*>(rsp + 16);
+    float4 b1n[SP][2], rsn[SP][2];
+#pragma unroll
+    for (int sp = 0; sp < SP; ++sp) {
+        b1n[sp][0] = *reinterpret_cast<const float4*>(b1p + sp * 32); b1n[sp][1] = *reinterpret_cast<const float4*>(b1p + sp * 32 + 16);
+        rsn[sp][0] = *reinterpret_cast<const float4*>(rsp + sp * 32); rsn[sp][1] = *reinterpret_cast<const float4*>(rsp + sp * 32 + 16);
+    }
     __syncthreads();
 #pragma unroll 2
-    for (int pr = 0; pr < FFN_PAIRS; ++pr) {
-        const int buf = pr & 1;
-        const float4 b10 = b1n0, b11 = b1n1, rs0 = rsn0, rs1 = rsn1;
-        if (pr + 1 < FFN_PAIRS) {                                   // next pair's fragments, biases and scales in flight
+    for (int g = 0; g < FFN_PAIRS / SP; ++g) {
+        const int buf = g & 1;
+        float4 b1c[SP][2], rsc[SP][2];
+#pragma unroll
+        for (int sp = 0; sp < SP; ++sp) { b1c[sp][0] = b1n[sp][0]; b1c[sp][1] = b1n[sp][1]; rsc[sp][0] = rsn[sp][0]; rsc[sp][1] = rsn[sp][1]; }
+        if (g + 1 < FFN_PAIRS / SP) {                               // next group's fragments, biases and scales in flight
 #pragma unroll
             for (int i = 0; i < NSTG; ++i)
-                if (tid + NTHR * i < FFN_FRAGS * 64) stg[i] = prep[(int64_t)(pr + 1) * (FFN_FRAGS * 64) + tid + NTHR * i];
-            b1n0 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32);
-            b1n1 = *reinterpret_cast<const float4*>(b1p + (pr + 1) * 32 + 16);
-            rsn0 = *reinterpret_cast<const float4*>(rsp + (pr + 1) * 32);
-            rsn1 = *reinterpret_cast<const float4*>(rsp + (pr + 1) * 32 + 16);
+                if (tid + NTHR * i < GFR) stg[i] = prep[(int64_t)(g + 1) * GFR + tid + NTHR * i];
+#pragma unroll
+            for (int sp = 0; sp < SP; ++sp) {
+                const int pn = (g + 1) * SP + sp;
+                b1n[sp][0] = *reinterpret_cast<const float4*>(b1p + pn * 32); b1n[sp][1] = *reinterpret_cast<const float4*>(b1p + pn * 32 + 16);
+                rsn[sp][0] = *reinterpret_cast<const float4*>(rsp + pn * 32); rsn[sp][1] = *reinterpret_cast<const float4*>(rsp + pn * 32 + 16);
+            }
         }
-        const u32x4* wf = &wl[buf][lane];
+#pragma unroll
+      for (int sp = 0; sp < SP; ++sp) {
+        const float4 b10 = b1c[sp][0], b11 = b1c[sp][1], rs0 = rsc[sp][0], rs1 = rsc[sp][1];
+        const u32x4* wf = &wl[buf][sp * (FFN_FRAGS * 64) + lane];
         // every weight fragment is read from LDS once per wave and pair and serves all NT token tiles
         // ---- u^T = W1 . h^T for the pair's two unit tiles, on top of the (scaled) bias of hidden unit 4q + r ----
         f32x4 ua[NT], ub[NT];
@@ -420,10 +438,11 @@ __device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_FRAGS * 64], cons
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) { TF_MM3(acc[tt][c], uh[tt], ul[tt], yh, yl) }
         }
-        if (pr + 1 < FFN_PAIRS) {
+      }
+        if (g + 1 < FFN_PAIRS / SP) {
 #pragma unroll
             for (int i = 0; i < NSTG; ++i)
-                if (tid + NTHR * i < FFN_FRAGS * 64) wl[buf ^ 1][tid + NTHR * i] = stg[i];
+                if (tid + NTHR * i < GFR) wl[buf ^ 1][tid + NTHR * i] = stg[i];
         }
         __syncthreads();
     }
@@ -458,7 +477,7 @@ __device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_FRAGS * 64], cons
 
 template <int NT>
 __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int layer) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];        // 32 KB
+    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_SP * FFN_FRAGS * 64];   // 32 KB per staged pair
     tf_ffn_body<NT>(wl, a, layer, (int)blockIdx.x);
 }
 // The FFN blocks of TWO encoders (price and process window of one network) as one grid: launched one after the
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int la
 // together they take 9.
 template <int NT>
 __global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_pair_kernel(TfArgs a, TfArgs b, int na, int layer) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_FRAGS * 64];
+    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_SP * FFN_FRAGS * 64];
     if ((int)blockIdx.x < na) tf_ffn_body<NT>(wl, a, layer, (int)blockIdx.x);
     else tf_ffn_body<NT>(wl, b, layer, (int)blockIdx.x - na);
 }
