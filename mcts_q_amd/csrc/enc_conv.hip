@@ -26,17 +26,21 @@ struct ConvLds {
 
 constexpr int CONV_SMAX = 26;
 constexpr int CXLD = (CONV_SMAX + 2) * 8 + 4;
+constexpr int CHLD = 72;                  // row stride of an fp16 plane (elements): 144 B keeps the b128 reads conflict-free
 struct ConvFwdLds {
-    float row[2][TILE * CLD];   // h1 rows in flight: row tp lives in slot tp & 1, written one step before it is read
+    // h1 rows in flight as split-fp16 planes (hi, lo) of 2^kh h1: row tp lives in slot tp & 1, written one step before
+    // it is read.  The PRODUCING lane splits its four values; as fp32 rows every wave split the whole 64-channel row
+    // again (64 of the step's ~190 vector instructions per wave, four times over per workgroup)
+    unsigned short rowp[2][2][TILE * CHLD];
     float xs[TILE * CXLD];
     PoolLds pool;
     float bound[3][4];          // per wave: largest |x| staged, largest sum_k |w1_c[k]|, largest |b1_c| (the h1 bound below)
 };
 
 // Forward.  h1 never exists as a whole image: at step t every wave computes its 16 channels of row t+3 (conv1 is
-// 3-6 fp32 MFMAs) into a two-slot LDS buffer, reads row t+2 ONCE, splits it into two fp16 planes in registers, and
-// multiplies rows t, t+1, t+2 (taps 0, 1, 2 of conv2) from three rotating register sets.  25 KB of LDS and
-// ~200 VGPRs let two workgroups (e.g. the price and the process window of one tile) share a CU.
+// 3-6 fp32 MFMAs), splits them into two fp16 planes and writes those into a two-slot LDS buffer, reads the fragments
+// of row t+2 ONCE, and multiplies rows t, t+1, t+2 (taps 0, 1, 2 of conv2) from three rotating register sets.
+// ~20 KB of LDS and ~180 VGPRs let two workgroups (e.g. the price and the process window of one tile) share a CU.
 template <bool SAVE>
 __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) {
     __shared__ __attribute__((aligned(16))) ConvFwdLds L;
@@ -115,6 +119,11 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
                              fmaxf(fmaxf(L.bound[1][0], L.bound[1][1]), fmaxf(L.bound[1][2], L.bound[1][3]));
     const int kh = f16_row_shift(hbound);
     const float sh = pow2i(kh), inv2 = pow2i(-(kh + s2j));          // row scale; un-scale of output channel j
+    // the rows live in LDS already scaled: conv1's weights and bias take the factor once (a power of two: the rows
+    // are the same bits times 2^kh), instead of sixteen multiplies per step and wave where the rows are split
+    const float b1s = b1j * sh, ish = pow2i(-kh);
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) w1f[kk] *= sh;
 
     // conv1 + ReLU for image row tp (1..S = time step tp-1; S+1 = the zero pad) -> LDS slot tp & 1
     auto conv1_row = [&](int tp) {
@@ -128,9 +137,12 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = real ? fmaxf(acc[r] + b1j, 0.0f) : 0.0f;
-            L.row[tp & 1][(4 * q + r) * CLD + j] = v;
-            if (SAVE && real) s.sv_h1[((int64_t)tp * Bp + row0 + 4 * q + r) * E + j] = v;
+            const float v = real ? fmaxf(acc[r] + b1s, 0.0f) : 0.0f;
+            unsigned short u0, u1;
+            split2h(v, u0, u1);
+            L.rowp[tp & 1][0][(4 * q + r) * CHLD + j] = u0;
+            L.rowp[tp & 1][1][(4 * q + r) * CHLD + j] = u1;
+            if (SAVE && real) s.sv_h1[((int64_t)tp * Bp + row0 + 4 * q + r) * E + j] = v * ish;
         }
     };
     // ---- conv2 + ReLU, attention pooling folded online ---------------------------------------------
@@ -138,12 +150,11 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
     // (three cross terms, fp32 accumulate: DESIGN.md section 3).
     struct RowFrag { u32x4 h[2], l[2]; };
     auto load_row = [&](int tp, RowFrag& f) {
-        const float4* p = reinterpret_cast<const float4*>(&L.row[tp & 1][(lane & 15) * CLD + 8 * q]);
+        const int o = (lane & 15) * CHLD + 8 * q;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            float4 a = p[8 * hf], b = p[8 * hf + 1];
-            a.x *= sh; a.y *= sh; a.z *= sh; a.w *= sh; b.x *= sh; b.y *= sh; b.z *= sh; b.w *= sh;
-            split8h(a, b, f.h[hf], f.l[hf]);
+            f.h[hf] = *reinterpret_cast<const u32x4*>(&L.rowp[tp & 1][0][o + 32 * hf]);
+            f.l[hf] = *reinterpret_cast<const u32x4*>(&L.rowp[tp & 1][1][o + 32 * hf]);
         }
     };
 #define CONV_MM6(ACC, F, HF, W)                                                                           \
