@@ -186,11 +186,17 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         load_row(1, f1);
         conv1_row(2);
         __syncthreads();
-        for (int t = 0; t < S; t += 3) {
+        // whole triples first: after three steps the three register sets are back in their roles, so the loop's back
+        // edge needs no register moves (with the window's tail handled inside the loop the compiler rotated 34
+        // registers per step); then the one or two steps that are left
+        int t = 0;
+        for (; t + 2 < S; t += 3) {
             step(t, f0, f1, f2);
-            if (t + 1 < S) step(t + 1, f1, f2, f0);
-            if (t + 2 < S) step(t + 2, f2, f0, f1);
+            step(t + 1, f1, f2, f0);
+            step(t + 2, f2, f0, f1);
         }
+        if (t < S) step(t, f0, f1, f2);
+        if (t + 1 < S) step(t + 1, f1, f2, f0);
     }
 #undef CONV_MM6
     pc.attend(L.pool, S & 1, S - 1, s.sv_score, row0, Bp);
