@@ -24,6 +24,10 @@
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
+#ifndef MCTSQ_GRU_PK
+#define MCTSQ_GRU_PK 1      // gate arithmetic on packed pairs of rows
+#endif
+
 namespace mctsq {
 
 constexpr int HLD = 72;     // LDS row stride of an h plane (bf16 elements): 144 B keeps b128 reads conflict-free
@@ -272,6 +276,20 @@ struct GruWave {
                 rp_sc += sc_stride;
             }
         }
+#if MCTSQ_GRU_PK
+        if (BND) {                                            // the common path, on packed pairs of rows
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const f32x2 sc = ((f32x2){p[0][2 * pp], p[0][2 * pp + 1]} + (f32x2){p[1][2 * pp], p[1][2 * pp + 1]}) +
+                                 ((f32x2){p[2][2 * pp], p[2][2 * pp + 1]} + (f32x2){p[3][2 * pp], p[3][2 * pp + 1]});
+                const f32x2 e = {fast_exp2(sc.x), fast_exp2(sc.y)};
+                const f32x2 a2 = e * (f32x2){hv[2 * pp], hv[2 * pp + 1]} + (f32x2){att[2 * pp], att[2 * pp + 1]};
+                const f32x2 l2 = (f32x2){lrun[2 * pp], lrun[2 * pp + 1]} + e;
+                att[2 * pp] = a2.x; att[2 * pp + 1] = a2.y; lrun[2 * pp] = l2.x; lrun[2 * pp + 1] = l2.y;
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float sc = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
@@ -359,12 +377,24 @@ struct GruWave {
         f32x4 accn = mfma_h(al[0], whi[2][0], bhnv), accm = mfma_h(al[1], whi[2][1], (f32x4){0, 0, 0, 0});
         accn = mfma_h(ah[0], wlo[2][0], accn);  accm = mfma_h(ah[1], wlo[2][1], accm);
         accn = mfma_h(ah[0], whi[2][0], accn);  accm = mfma_h(ah[1], whi[2][1], accm);
+        // Gate arithmetic on PAIRS of rows (packed fp32 instructions process two values per lane at the rate of one):
+        // the step is bound by vector + transcendental issue once the matrix part is halved
         float rg[4], zg[4];
+#if MCTSQ_GRU_PK
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x2 er = (f32x2){accr[2 * p], accr[2 * p + 1]} * esr, ez = (f32x2){accz[2 * p], accz[2 * p + 1]} * esz;
+            const f32x2 dr = (f32x2){fast_exp2(er.x), fast_exp2(er.y)} + 1.0f, dz = (f32x2){fast_exp2(ez.x), fast_exp2(ez.y)} + 1.0f;
+            rg[2 * p] = fast_rcp(dr.x); rg[2 * p + 1] = fast_rcp(dr.y);
+            zg[2 * p] = fast_rcp(dz.x); zg[2 * p + 1] = fast_rcp(dz.y);
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             rg[r] = fast_rcp(1.0f + fast_exp2(esr * accr[r]));      // sigmoid of 2^-k accr
             zg[r] = fast_rcp(1.0f + fast_exp2(esz * accz[r]));
         }
+#endif
         // training record, lane-major (kernels.hpp: GruSlot): the lane's four rows of one unit are one 16-byte store, a
         // wave's store instruction one contiguous KB.  Uniform 64-bit base (scalar registers) + 32-bit lane offset: no
         // vector address math.  Each field leaves as soon as it exists (r, z here, under the n gate's products; n, W_hn h
@@ -376,6 +406,29 @@ struct GruWave {
             *reinterpret_cast<f32x4*>(rp_z + lo) = (f32x4){zg[0], zg[1], zg[2], zg[3]};
         }
         f32x4 svn, svhn, svh;
+#if MCTSQ_GRU_PK
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x2 hn = (f32x2){accn[2 * p], accn[2 * p + 1]} + (f32x2){accm[2 * p], accm[2 * p + 1]};   // 2^k (W_hn h + b_hn)
+            const f32x2 rg2 = {rg[2 * p], rg[2 * p + 1]}, zg2 = {zg[2 * p], zg[2 * p + 1]};
+            const f32x2 an = ((f32x2){acci[2 * p], acci[2 * p + 1]} + rg2 * hn) * esn;
+            const f32x2 dn = (f32x2){fast_exp2(an.x), fast_exp2(an.y)} + 1.0f;
+            const f32x2 ng = 1.0f - 2.0f * (f32x2){fast_rcp(dn.x), fast_rcp(dn.y)};                           // tanh of 2^-k (...)
+            const f32x2 hp = {hh[nxt][2 * p], hh[nxt][2 * p + 1]};
+            const f32x2 hnew = ng + zg2 * (hp - ng);
+            const f32x2 hs = hnew * (float)(1 << F16_TOP);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int r = 2 * p + e, i = 4 * q + r;
+                unsigned short u0, u1;
+                split2h(hs[e], u0, u1);
+                L.hb[0][nxt][i * HLD + j] = u0;
+                L.hb[1][nxt][i * HLD + j] = u1;
+                if (SAVE) { svn[r] = ng[e]; svhn[r] = hn[e] * invn; svh[r] = hnew[e]; }
+                hh[cur][r] = hnew[e];
+            }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
@@ -389,6 +442,7 @@ struct GruWave {
             if (SAVE) { svn[r] = ng; svhn[r] = hn * invn; svh[r] = hnew; }
             hh[cur][r] = hnew;
         }
+#endif
         if (SAVE) {
             *reinterpret_cast<f32x4*>(rp_n + lo) = svn;
             *reinterpret_cast<f32x4*>(rp_hn + lo) = svhn;
