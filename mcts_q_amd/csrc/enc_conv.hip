@@ -169,9 +169,15 @@ __global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) 
         if (t > 0) pc.attend(L.pool, cur, t - 1, s.sv_score, row0, Bp);
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] = fmaxf(fmaf((acc0[r] + acc1[r]) + acc2[r], inv2, b2j), 0.0f);
-            if (SAVE) s.sv_h2[((int64_t)t * Bp + row0 + 4 * q + r) * E + j] = v[r];
+        for (int pp = 0; pp < 2; ++pp) {                         // packed pairs of rows: the step is bound by vector issue
+            const f32x2 sm = ((f32x2){acc0[2 * pp], acc0[2 * pp + 1]} + (f32x2){acc1[2 * pp], acc1[2 * pp + 1]}) +
+                             (f32x2){acc2[2 * pp], acc2[2 * pp + 1]};
+            const f32x2 y = sm * inv2 + b2j;
+            v[2 * pp] = fmaxf(y.x, 0.0f); v[2 * pp + 1] = fmaxf(y.y, 0.0f);
+        }
+        if (SAVE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s.sv_h2[((int64_t)t * Bp + row0 + 4 * q + r) * E + j] = v[r];
         }
         pc.publish(L.pool, nxt, v);
         __syncthreads();

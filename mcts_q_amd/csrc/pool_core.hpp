@@ -31,7 +31,8 @@ struct PoolCore {
         float4 ps;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = v[r];
-        ps.x = row16_sum(awj * v[0]); ps.y = row16_sum(awj * v[1]); ps.z = row16_sum(awj * v[2]); ps.w = row16_sum(awj * v[3]);
+        const f32x2 a01 = (f32x2){v[0], v[1]} * awj, a23 = (f32x2){v[2], v[3]} * awj;      // packed pairs of rows
+        ps.x = row16_sum(a01.x); ps.y = row16_sum(a01.y); ps.z = row16_sum(a23.x); ps.w = row16_sum(a23.y);
         // one lane per row group stores its four sums as 16 bytes; the others write theirs to a slot of their own:
         // no branch around the store (gru_core.hpp: GruWave::publish)
         float* dst = jl == 0 ? &L.spart[buf][wq][4 * q] : &L.dump[wq][(16 * q + jl) * 4];
@@ -42,12 +43,14 @@ struct PoolCore {
         float4 sp[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) sp[w] = *reinterpret_cast<const float4*>(&L.spart[buf][w][4 * q]);
-        const float p[4][4] = {{sp[0].x, sp[0].y, sp[0].z, sp[0].w}, {sp[1].x, sp[1].y, sp[1].z, sp[1].w},
-                               {sp[2].x, sp[2].y, sp[2].z, sp[2].w}, {sp[3].x, sp[3].y, sp[3].z, sp[3].w}};
+        // the four waves' partial scores summed on packed pairs of rows
+        const f32x2 s01 = (((f32x2){sp[0].x, sp[0].y} + (f32x2){sp[1].x, sp[1].y}) + ((f32x2){sp[2].x, sp[2].y} + (f32x2){sp[3].x, sp[3].y})) + ab;
+        const f32x2 s23 = (((f32x2){sp[0].z, sp[0].w} + (f32x2){sp[1].z, sp[1].w}) + ((f32x2){sp[2].z, sp[2].w} + (f32x2){sp[3].z, sp[3].w})) + ab;
+        const float scs[4] = {s01.x, s01.y, s23.x, s23.y};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * q + r;
-            const float sc = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) + ab;
+            const float sc = scs[r];
             if (SAVE && wq == 0 && jl == 0) sv_score[(int64_t)t * Bp + row0 + i] = sc;
             const float d = sc - mrun[r];
             const float e = fast_exp2(-fabsf(d));
