@@ -323,18 +323,15 @@ def main():
         def run_train(Bg, kind):
             # the SAME uniforms on every rank (shared seed): each rank serves the draws in its mass interval
             u_all = torch.from_numpy(np.random.RandomState(3654).random_sample((tsteps + twarm, Bg))).to(dev)
-            sampler = parallel.ShardedSampler(buf, group) if world > 1 else None
+            bcap = parallel.draw_capacity(Bg, world)
 
             def train_step(i):
                 if world == 1:
                     L.step(buf, u_all[i], tau=0.005)                       # DQNModel.update() + target sync: one call
-                    return
                 else:
-                    smp = sampler.sample(u_all[i])                         # no host read of device memory
-                    batch, w, idx = smp["batch"], smp["w"], smp["idx"]
-                abs_td = L.compute_grad(batch, w, global_batch=Bg)
-                L.apply_grad(tau=0.005)
-                buf.update_priorities(idx, abs_td)
+                    # two library calls around ONE all-reduce over [gradient | loss | weight maxima], plus the
+                    # all-gather of the shards' (mass, size) pairs; no host read of device memory
+                    L.step_sharded(buf, u_all[i], tau=0.005, bcap=bcap)
 
             settle()                                           # the replay set-up above left the device idle
             for i in range(twarm):
@@ -350,7 +347,7 @@ def main():
             twall = max_over_ranks(time.perf_counter() - t0)
             enc_fl, head_fl = forward_flops(spec)
             step_flops = 4 * (enc_fl + head_fl) * Bg           # policy fwd + 2 x bwd + target fwd
-            rows = Bg if world == 1 else sampler.bcap
+            rows = Bg if world == 1 else bcap
             act_bytes = sum(S * rows * 64 * 4 * 5 for S in spec.seq)      # r, z, n, W_hn h, h per GRU step: written, read back
             step_bytes = 2 * act_bytes + sum(S * rows * 256 * 4 * 2 for S in spec.seq) + 2 * 364 * rows + 16 * spec.n_flat * 4
             ach = step_flops / (twall / tsteps) / 1e12
@@ -360,6 +357,7 @@ def main():
                     "gpu_ms_per_step_events_rank0": tev0.elapsed_ms(tev1) / tsteps,
                     "global_batch": Bg, "rows_per_rank": rows, "replay_entries_per_gpu": N,
                     "scaling": kind, "transitions_per_s": tsteps * Bg / twall, "loss_last": float(L.loss.item()),
+                    "collectives_per_step": (0 if world == 1 else 2),
                     "roofline": {"bound": "latency chain (64 tiles of 16 transitions on 256 CUs; see DESIGN 5b)",
                                  "flops_per_step": step_flops, "achieved": ach, "unit": "TFLOP/s",
                                  "peak": FP32_MATRIX_PEAK_TFLOPS, "frac": ach / FP32_MATRIX_PEAK_TFLOPS,

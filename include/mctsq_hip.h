@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MCTSQ_ABI_VERSION 4
+#define MCTSQ_ABI_VERSION 5
 
 /* encoder kinds (dqn_per.py:181-203) */
 enum { MCTSQ_ENC_CONV = 1, MCTSQ_ENC_GRU = 2, MCTSQ_ENC_TRANSFORMER = 3, MCTSQ_ENC_MLP = 4 };
@@ -194,9 +194,37 @@ typedef struct {
      *    on the next call, or call mctsq_dqn_prepare / mctsq_q_prepare before using the fragments elsewhere.  Same
      *    results; the re-split launch and its boundary leave the step's serial chain. */
     int64_t resplit_first;
+    /* ---- data-parallel form only (mctsq_per_dqn_step_begin / _finish below); zero for mctsq_per_dqn_step.
+     * world ranks each own one replay shard; B (above) is the number of GLOBAL draws in d_u (identical on every
+     * rank), bcap the rows this rank provisions for its share of them (a multiple of 16; unused rows are padding). */
+    int64_t world, rank, bcap;
+    const uint64_t* d_shard_mass; const int64_t* d_shard_size; /* [world]: all-gathered mctsq_per_total_mass pairs */
+    int32_t* d_count;        /* [2] out: draws this rank kept / draws that did not fit bcap (must stay 0) */
+    int32_t* d_draw;         /* [bcap] out: positions in d_u of the rows (-1 = padding) */
+    float* d_exchange;       /* [2 * world] fp32, directly behind the loss word's 16-float block (see below) */
 } mctsq_step_args;
 int64_t mctsq_per_dqn_step_workspace_bytes(const mctsq_net_desc* net, int64_t B);
 int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_args* args, void* stream);
+
+/* ---- the same step for W data-parallel ranks (no reference counterpart: SURVEY.md section 8e), as TWO calls around
+ * the one gradient collective.  Per step and rank:
+ *     mctsq_per_total_mass -> all-gather of the (mass, size) pairs             [collective 1: 16 bytes per rank]
+ *     mctsq_per_dqn_step_begin : shard selection of the B global draws (mctsq_per_shard_select), bcap rows sampled and
+ *         gathered from this rank's shard with the totals of the whole buffer (mctsq_per_sample_shard), loss and
+ *         backward with loss_scale = bcap / B on the RAW importance weights (N p_i)^-beta, priority write-back.
+ *         Leaves ONE contiguous fp32 block ready to be summed over ranks:
+ *             d_grad [total] | d_loss [16] (word 0 used) | d_exchange [2 * world]
+ *         (the caller lays the three out in that order: d_loss = d_grad + total, d_exchange = d_loss + 16), where
+ *         d_exchange[2 r], [2 r + 1] = (hi, lo) fp32 halves of rank r's largest raw weight, the other ranks' slots 0.
+ *     all-reduce(SUM) over that block                                          [collective 2: RCCL]
+ *     mctsq_per_dqn_step_finish : max over the exchanged slots = the global weight maximum the reference divides by
+ *         (dqn_per.py:301); loss and gradient are linear in 1 / max, so the division is applied here: loss word and
+ *         gradient are scaled in place, then clip_grad_norm_ / Adam (/ Polyak when tau >= 0) as in the one-call form.
+ * Every rank ends with identical parameters.  Against mctsq_per_dqn_step on the concatenated buffer: same indices,
+ * same |td| priorities; the weights enter as fp32(w_raw) / max instead of fp32(w_raw / max), i.e. parameters agree
+ * to fp32 rounding (tests/test_gpu_dataparallel.py).  d_ws: mctsq_per_dqn_step_workspace_bytes(net, bcap). */
+int mctsq_per_dqn_step_begin(const mctsq_net_desc* net, const mctsq_step_args* args, void* stream);
+int mctsq_per_dqn_step_finish(const mctsq_net_desc* net, const mctsq_step_args* args, void* stream);
 
 /* ---- clip_grad_norm_(max_norm) + Adam.step + Polyak target update (dqn_per.py:471-472,
  * 510-516) over the flat buffers, n floats each.  step is 1-based.  tau < 0 skips the target

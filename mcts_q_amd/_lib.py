@@ -36,7 +36,9 @@ class StepArgs(C.Structure):
                                       "d_prep_target", "d_prep_bwd")]
                 + [(n, _f64) for n in ("gamma", "lr", "beta1", "beta2", "eps", "max_norm", "tau")]
                 + [("adam_step", _i64), ("d_u", _vp), ("B", _i64), ("d_loss", _vp), ("d_gnorm", _vp), ("d_wmax", _vp),
-                   ("d_ws", _vp), ("ws_bytes", _i64), ("resplit_first", _i64)])
+                   ("d_ws", _vp), ("ws_bytes", _i64), ("resplit_first", _i64)]
+                + [(n, _i64) for n in ("world", "rank", "bcap")]
+                + [(n, _vp) for n in ("d_shard_mass", "d_shard_size", "d_count", "d_draw", "d_exchange")])
 
 # name -> (restype, argtypes); every symbol declared in include/mctsq_hip.h
 SIGNATURES = {
@@ -63,6 +65,8 @@ SIGNATURES = {
                                        _f32, _f32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mctsq_per_dqn_step_workspace_bytes": (_i64, [_ND, _i64]),
     "mctsq_per_dqn_step": (_i32, [_ND, C.POINTER(StepArgs), _vp]),
+    "mctsq_per_dqn_step_begin": (_i32, [_ND, C.POINTER(StepArgs), _vp]),
+    "mctsq_per_dqn_step_finish": (_i32, [_ND, C.POINTER(StepArgs), _vp]),
     "mctsq_clip_adam_polyak_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f64, _f64, _f64, _f64, _f64,
                                          _f64, _vp, _vp, _i64, _vp, _i64, _vp]),
     "mctsq_optim_workspace_bytes": (_i64, []),

@@ -138,4 +138,10 @@ struct ReduceExtras {
 int wgrad_reduce_blocks(const WJobList& jl);
 int launch_wgrad_reduce(const WJobList& jl, const float* partials, float* grad, const ReduceExtras* ex, hipStream_t st);
 
+// mctsq_clip_adam_polyak_ex with the data-parallel exchange block (optim.hip): d_exchange [2 * world] or NULL
+int clip_adam_polyak_impl(float* d_params, const float* d_grad, float* d_m, float* d_v, float* d_target, int64_t n,
+                          int64_t step, double lr, double beta1, double beta2, double eps, double max_norm, double tau,
+                          float* d_gnorm, const double* d_sumsq_parts, int64_t nparts, void* d_ws, int64_t ws_bytes,
+                          const float* d_exchange, int world, float* d_grad_scaled, float* d_loss_io, void* stream);
+
 }  // namespace mctsq

@@ -775,6 +775,7 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
 namespace {
 struct StepPlan {
     int64_t idx, phys, w, abs_td, sprice, sprocess, sgas, nprice, nprocess, ngas, act, rew, done, sumsq, grad_ws;
+    int64_t targets, w64, draw, wmax;                        // data-parallel form: shard selection / raw weights
     int64_t total;                                           // bytes
 };
 int64_t take(int64_t& pos, int64_t bytes) {
@@ -790,6 +791,7 @@ int make_step_plan(const mctsq_net_desc* net, const NetLayout& L, int64_t B, Ste
     S->nprice = take(pos, B * L.enc[0].S * L.enc[0].Fd * 4); S->nprocess = take(pos, B * L.enc[1].S * L.enc[1].Fd * 4);
     S->ngas = take(pos, B * L.enc[2].S * L.enc[2].Fd * 4);
     S->act = take(pos, B * 4); S->rew = take(pos, B * 4); S->done = take(pos, B * 4);
+    S->targets = take(pos, B * 8); S->w64 = take(pos, B * 8); S->draw = take(pos, B * 4); S->wmax = take(pos, 8);
     const int64_t np = mctsq_dqn_grad_sumsq_parts(net);
     if (np < 0) return -1;
     S->sumsq = take(pos, np * 8);
@@ -879,4 +881,114 @@ extern "C" int mctsq_per_dqn_step(const mctsq_net_desc* net, const mctsq_step_ar
     // (the priority write-back ran first on the second helper lane, which the reduction joined)
     if (rc) return rc;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The data-parallel form of the step (include/mctsq_hip.h): everything up to the flat gradient / everything behind the
+// gradient all-reduce.  Same kernels as the one-call form; the shard selection is one more (single-workgroup) launch,
+// the importance weights stay raw until the finish call has the global maximum.
+namespace {
+int check_dp_args(const NetLayout& L, const mctsq_step_args* a) {
+    MCTSQ_CHECK(a != nullptr, "step arguments are NULL");
+    MCTSQ_CHECK(L.enc[0].S == 25 && L.enc[0].Fd == 1 && L.enc[1].S == 10 && L.enc[1].Fd == 6 && L.enc[2].S == 3 &&
+                    L.enc[2].Fd == 2, "the replay ring stores 25x1 / 10x6 / 3x2 windows (MCTSQ_STATE_ROW)");
+    MCTSQ_CHECK(a->world >= 1 && a->world <= 64 && a->rank >= 0 && a->rank < a->world, "bad shard geometry (world %lld, rank %lld)",
+                (long long)a->world, (long long)a->rank);
+    MCTSQ_CHECK(a->B >= 1 && a->B < ((int64_t)1 << 31), "global draw count must be >= 1");
+    MCTSQ_CHECK(a->bcap >= 16 && a->bcap % 16 == 0 && a->bcap <= 16384, "bcap must be a multiple of 16 in [16, 16384]");
+    MCTSQ_CHECK(a->d_ws && a->d_loss && a->d_grad && a->d_m && a->d_v && a->d_params && a->d_target_params && a->d_exchange,
+                "NULL device pointer");
+    MCTSQ_CHECK(a->d_loss == a->d_grad + L.total && a->d_exchange == a->d_loss + 16,
+                "d_grad | d_loss | d_exchange must be one contiguous block (total, 16, 2 * world floats)");
+    MCTSQ_CHECK(((uintptr_t)a->d_ws & 255) == 0, "workspace must be 256-byte aligned");
+    return 0;
+}
+}  // namespace
+
+extern "C" int mctsq_per_dqn_step_begin(const mctsq_net_desc* net, const mctsq_step_args* a, void* stream) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    if (check_dp_args(L, a)) return -1;
+    MCTSQ_CHECK(a->d_u && a->d_shard_mass && a->d_shard_size && a->d_count && a->d_tree && a->d_prio && a->d_stamp,
+                "NULL device pointer");
+    MCTSQ_CHECK(a->capacity >= 1 && a->size >= 0 && a->size <= a->capacity && a->head >= 0 && a->head < a->capacity &&
+                    (a->size == a->capacity || a->head == 0), "bad ring geometry");
+    MCTSQ_CHECK(a->mass_capacity >= a->capacity && a->mass_capacity <= (int64_t)1 << 36, "mass_capacity out of range");
+    MCTSQ_CHECK(a->d_per_ws && a->per_ws_bytes >= PER_WS_CTRL_BYTES && ((uintptr_t)a->d_per_ws & 15) == 0,
+                "sampling workspace too small or misaligned");
+    const int64_t R = a->bcap;
+    StepPlan S;
+    if (make_step_plan(net, L, R, &S)) return -1;
+    MCTSQ_CHECK(a->ws_bytes >= S.total, "workspace too small: %lld < %lld bytes", (long long)a->ws_bytes, (long long)S.total);
+    char* ws = (char*)a->d_ws;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t* d_idx = (int64_t*)(ws + S.idx); int64_t* d_phys = (int64_t*)(ws + S.phys);
+    float* d_w = (float*)(ws + S.w); float* d_abs_td = (float*)(ws + S.abs_td);
+    float* sp = (float*)(ws + S.sprice); float* sc = (float*)(ws + S.sprocess); float* sg = (float*)(ws + S.sgas);
+    float* np_ = (float*)(ws + S.nprice); float* nc = (float*)(ws + S.nprocess); float* ng = (float*)(ws + S.ngas);
+    int32_t* act = (int32_t*)(ws + S.act); float* rew = (float*)(ws + S.rew); float* done = (float*)(ws + S.done);
+    unsigned long long* targets = (unsigned long long*)(ws + S.targets);
+    double* w64 = (double*)(ws + S.w64);
+    int32_t* draw = a->d_draw ? a->d_draw : (int32_t*)(ws + S.draw);
+    double* wmax = a->d_wmax ? a->d_wmax : (double*)(ws + S.wmax);
+    const bool resplit_first = a->resplit_first != 0;
+    DqnPrepArgs pa;
+    SamplePassengers extra{nullptr, a->d_grad, L.total};     // the gradient fill rides along (not the exchange slots:
+    if (resplit_first) {                                     // the sampling launch's last workgroup writes all of them)
+        MCTSQ_CHECK((a->d_prep_policy && a->d_prep_target) || prepared_bytes(L) == 0, "NULL prepared-weights pointer");
+        MCTSQ_CHECK(a->d_prep_bwd || prep_bwd_bytes(L) == 0, "NULL backward prepared-weights pointer");
+        MCTSQ_CHECK((((uintptr_t)a->d_prep_policy | (uintptr_t)a->d_prep_target | (uintptr_t)a->d_prep_bwd) & 15) == 0,
+                    "prepared buffers must be 16-byte aligned");
+        if (one_launch_prepare(L)) {
+            fill_dqn_prep(L, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd, &pa);
+            extra.prep = &pa;
+        } else if (mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target,
+                                     a->d_prep_bwd, stream)) {
+            return -1;
+        }
+    }
+    // this rank's share of the global draws, compacted (draw order kept); rows behind d_count[0] are padding
+    if (launch_per_shard_select(a->d_u, a->B, (const unsigned long long*)a->d_shard_mass, (int)a->world, (int)a->rank, R,
+                                targets, draw, a->d_count, st))
+        return -1;
+    PerGatherArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    MCTSQ_CHECK(a->d_states && a->d_next_states && a->d_actions && a->d_rewards && a->d_dones, "NULL device pointer");
+    ga.states = a->d_states; ga.next_states = a->d_next_states; ga.actions = a->d_actions; ga.rewards = a->d_rewards;
+    ga.dones = a->d_dones; ga.phys = d_phys; ga.B = R;
+    ga.sprice = sp; ga.sprocess = sc; ga.sgas = sg; ga.nprice = np_; ga.nprocess = nc; ga.ngas = ng;
+    ga.act = act; ga.rew = rew; ga.done = done;
+    const ShardWeightOut raw{d_w, a->d_exchange, (int)a->world, (int)a->rank};
+    if (launch_per_sample_shard((const unsigned long long*)a->d_tree, a->d_prio, a->capacity, a->head, a->size, targets,
+                                a->d_count, R, a->alpha, a->beta, a->mass_capacity,
+                                (const unsigned long long*)a->d_shard_mass, a->d_shard_size, (int)a->world, d_idx, d_phys,
+                                w64, wmax, a->d_per_ws, &ga, st, &extra, &raw))
+        return -1;
+    PerUpdateHook upd{(unsigned long long*)a->d_tree, a->d_prio, a->d_stamp, a->capacity, a->head, a->size, d_idx,
+                      a->alpha, a->mass_capacity, true};
+    DqnPrep pp{a->d_prep_policy, a->d_prep_target, a->d_prep_bwd};
+    const int rc = dqn_grad_entry(net, &pp, a->d_params, a->d_target_params, sp, sc, sg, np_, nc, ng, act, rew, done, d_w,
+                                  (float)a->gamma, (float)((double)R / (double)a->B), R, a->d_grad, a->d_loss, d_abs_td,
+                                  nullptr, nullptr, nullptr, ws + S.grad_ws, S.total - S.grad_ws, stream, &upd);
+    return rc < 0 ? rc : 0;
+}
+
+extern "C" int mctsq_per_dqn_step_finish(const mctsq_net_desc* net, const mctsq_step_args* a, void* stream) {
+    NetLayout L;
+    if (build_layout(net, &L)) return -1;
+    if (check_dp_args(L, a)) return -1;
+    StepPlan S;
+    if (make_step_plan(net, L, a->bcap, &S)) return -1;
+    MCTSQ_CHECK(a->ws_bytes >= S.total, "workspace too small: %lld < %lld bytes", (long long)a->ws_bytes, (long long)S.total);
+    // the norm is that of the SUMMED gradient: recomputed here (redundantly per block for the small networks, from
+    // partials in the step workspace otherwise); the reduction's own pieces describe this rank's share only
+    int rc = clip_adam_polyak_impl(a->d_params, a->d_grad, a->d_m, a->d_v, a->d_target_params, L.total, a->adam_step, a->lr,
+                                   a->beta1, a->beta2, a->eps, a->max_norm, a->tau, a->d_gnorm, nullptr, 0,
+                                   (char*)a->d_ws + S.sumsq, mctsq_optim_workspace_bytes(), a->d_exchange, (int)a->world,
+                                   a->d_grad, a->d_loss, stream);
+    if (rc) return rc;
+    if (!a->resplit_first)
+        rc = mctsq_dqn_prepare(net, a->d_params, a->d_target_params, a->d_prep_policy, a->d_prep_target, a->d_prep_bwd,
+                               stream);
+    return rc;
 }

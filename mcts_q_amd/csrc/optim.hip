@@ -3,6 +3,7 @@
 // HBM-bound streaming: 5 reads + 4 writes of 4 bytes per parameter, float4-vectorised.
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "learner.hpp"
 
 namespace mctsq {
 
@@ -30,7 +31,19 @@ struct AdamArgs {
     const double* part;         // partial sums of squares of the gradient (another launch made them), fixed order
     int npart;
     float* gnorm_out;
+    // data-parallel step: the summed gradient (and loss) still carry the global weight maximum; its candidates are
+    // the (hi, lo) fp32 pairs of the exchange block.  NULL: scale 1 (every product below is then exact: x * 1.0f).
+    const float* wmax_slots; int wmax_world;
+    float* g_scaled_out;        // the gradient with the scale applied (unclipped), written back in place, or NULL
+    float* loss_io;             // the summed loss, scaled in place by block 0, or NULL
 };
+
+__device__ __forceinline__ float exchange_scale(const AdamArgs& a) {
+    if (!a.wmax_slots) return 1.0f;
+    double mx = 0.0;
+    for (int r = 0; r < a.wmax_world; ++r) mx = fmax(mx, (double)a.wmax_slots[2 * r] + (double)a.wmax_slots[2 * r + 1]);
+    return mx > 0.0 ? (float)(1.0 / mx) : 0.0f;
+}
 
 // FUSED_NORM: every block computes the global sum of squares itself, all in the same fixed order (thread t takes
 // the float4s t, t + 256, ...; wave shuffle; four wave sums), instead of reading partials a separate launch made:
@@ -41,6 +54,8 @@ template <bool FUSED_NORM>
 __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_polyak_kernel(AdamArgs a) {
     __shared__ float s_coef;
     __shared__ double s_red[ADAM_THREADS / 64];
+    const float gs = exchange_scale(a);
+    if (a.loss_io && blockIdx.x == 0 && threadIdx.x == 0 && a.wmax_slots) *a.loss_io = *a.loss_io * gs;
     if (FUSED_NORM) {
         const int64_t n4 = a.n >> 2;
         double acc = 0.0;
@@ -61,7 +76,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_polyak_kernel(AdamArgs
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int i = 0; i < ADAM_THREADS / 64; ++i) t += s_red[i];
-            const float total = (float)sqrt(t);
+            const float total = (float)sqrt(t) * gs;
             s_coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
             if (blockIdx.x == 0 && a.gnorm_out) *a.gnorm_out = total;
         }
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_polyak_kernel(AdamArgs
         }
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if (threadIdx.x == 0) {
-            const float total = (float)sqrt(acc);
+            const float total = (float)sqrt(acc) * gs;
             s_coef = fminf(a.max_norm / (total + 1e-6f), 1.0f);
             if (blockIdx.x == 0 && a.gnorm_out) *a.gnorm_out = total;
         }
@@ -97,9 +112,11 @@ __global__ __launch_bounds__(ADAM_THREADS) void clip_adam_polyak_kernel(AdamArgs
         float4 m = reinterpret_cast<float4*>(a.m)[i];
         float4 v = reinterpret_cast<float4*>(a.v)[i];
         float* pp = &p.x; float* pm = &m.x; float* pv = &v.x; const float* pg = &g4.x;
+        if (a.g_scaled_out)
+            reinterpret_cast<float4*>(a.g_scaled_out)[i] = make_float4(g4.x * gs, g4.y * gs, g4.z * gs, g4.w * gs);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float g = pg[c] * coef;
+            const float g = (pg[c] * gs) * coef;
             pm[c] = pm[c] + (g - pm[c]) * one_m_b1;                      // exp_avg.lerp_(g, 1-b1)
             pv[c] = __fadd_rn(__fmul_rn(pv[c], a.b2), __fmul_rn(__fmul_rn(g, g), one_m_b2));
             const float denom = sqrtf(pv[c]) / a.bc2_sqrt + a.eps;
@@ -149,6 +166,17 @@ extern "C" int mctsq_clip_adam_polyak_ex(float* d_params, const float* d_grad, f
                                          double beta2, double eps, double max_norm, double tau, float* d_gnorm,
                                          const double* d_sumsq_parts, int64_t nparts, void* d_ws, int64_t ws_bytes,
                                          void* stream) {
+    return mctsq::clip_adam_polyak_impl(d_params, d_grad, d_m, d_v, d_target, n, step, lr, beta1, beta2, eps, max_norm, tau,
+                                        d_gnorm, d_sumsq_parts, nparts, d_ws, ws_bytes, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// exchange != NULL: the data-parallel form (mctsq_per_dqn_step_finish): gradient and loss are divided by the largest
+// of the `world` exchanged weight maxima inside the pass; the scaled (unclipped) gradient replaces d_grad
+int mctsq::clip_adam_polyak_impl(float* d_params, const float* d_grad, float* d_m, float* d_v, float* d_target,
+                                 int64_t n, int64_t step, double lr, double beta1, double beta2, double eps,
+                                 double max_norm, double tau, float* d_gnorm, const double* d_sumsq_parts,
+                                 int64_t nparts, void* d_ws, int64_t ws_bytes, const float* d_exchange, int world,
+                                 float* d_grad_scaled, float* d_loss_io, void* stream) {
     MCTSQ_CHECK(d_params && d_grad && d_m && d_v, "NULL device pointer");
     MCTSQ_CHECK(n > 0 && n % 16 == 0, "flat buffer length must be a positive multiple of 16 (padded layout)");
     MCTSQ_CHECK(step >= 1, "Adam step is 1-based");
@@ -169,6 +197,9 @@ extern "C" int mctsq_clip_adam_polyak_ex(float* d_params, const float* d_grad, f
     a.eps = (float)eps; a.max_norm = (float)max_norm; a.tau = (float)tau; a.one_m_tau = (float)(1.0 - tau);
     a.part = d_sumsq_parts ? d_sumsq_parts : part; a.npart = d_sumsq_parts ? (int)nparts : NPART;
     a.gnorm_out = d_gnorm;
+    a.wmax_slots = d_exchange; a.wmax_world = world; a.g_scaled_out = d_exchange ? d_grad_scaled : nullptr;
+    a.loss_io = d_exchange ? d_loss_io : nullptr;
+    MCTSQ_CHECK(!d_exchange || (world >= 1 && world <= 64), "bad exchange geometry");
     MCTSQ_CHECK(tau < 0.0 || d_target, "target buffer is NULL but tau >= 0");
     const unsigned agrid = (stream_grid(n >> 2) * 256 + ADAM_THREADS - 1) / ADAM_THREADS;
     if (fused) hipLaunchKernelGGL(clip_adam_polyak_kernel<true>, dim3(agrid), dim3(ADAM_THREADS), 0, st, a);

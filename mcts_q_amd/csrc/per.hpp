@@ -56,11 +56,15 @@ int launch_per_sample_at(const per_u64* tree, const double* prio, int64_t cap, i
                          const per_u64* targets, int64_t B, double alpha, double beta, int64_t mass_cap,
                          double n_total, double mass_total, int64_t* idx, int64_t* phys, double* w64, double* wmax,
                          hipStream_t st);
+// raw != NULL (data-parallel learner step): additionally fp32 raw weights per row and the (hi, lo) halves of their
+// maximum in this rank's pair of `slots` [2 * world] (the other pairs are written as zeros)
+struct ShardWeightOut { float* w_raw; float* slots; int world, rank; };
 int launch_per_sample_shard(const per_u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
                             const per_u64* targets, const int32_t* count, int64_t bcap, double alpha, double beta,
                             int64_t mass_cap, const per_u64* shard_mass, const int64_t* shard_size, int world,
                             int64_t* idx, int64_t* phys, double* w64, double* wmax, void* ws,
-                            const PerGatherArgs* ga, hipStream_t st);
+                            const PerGatherArgs* ga, hipStream_t st, const SamplePassengers* extra = nullptr,
+                            const ShardWeightOut* raw = nullptr);
 int launch_per_shard_select(const double* u, int64_t B, const per_u64* shard_mass, int world, int rank, int64_t bcap,
                             per_u64* targets, int32_t* draw, int32_t* out, hipStream_t st);
 int launch_per_normalize(const double* w64, int64_t B, const double* wmax, float* w, hipStream_t st);

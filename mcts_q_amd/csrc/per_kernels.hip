@@ -128,6 +128,9 @@ struct PerSampleArgs {
     const u64* shard_mass; const int64_t* shard_size; int world;   // ... or on the device
     int64_t *idx_out, *phys_out; double* w64;
     float* w; double* wmax; unsigned* ticket;     // fused normalisation (w may be NULL)
+    float* w_raw;                 // data-parallel step: fp32 RAW weights (the division by the global maximum happens
+    float* wmax_slots;            // behind the gradient all-reduce); [2 * slot_world] fp32: (hi, lo) halves of this
+    int slot_world, slot_rank;    // rank's largest raw weight in its own pair of slots, zeros in the others
     PerGatherArgs ga;             // fused gather when ga.states != NULL
     int nsample;                  // workgroups that sample; behind them the passengers (per.hpp): nprep workgroups
     int nprep;                    // re-split weights (prep), the rest zero `zero`
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
                 a.phys_out[d] = 0;
             }
             __hip_atomic_store(&a.w64[d], wraw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.w_raw) a.w_raw[d] = (float)wraw;
         }
     }
     if (gath) {
@@ -323,6 +327,10 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     if (a.w)
         for (int64_t i = tid; i < a.B; i += SMP_THREADS)
             a.w[i] = mx > 0.0 ? (float)(__hip_atomic_load(&a.w64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / mx) : 0.0f;
+    if (a.wmax_slots && tid < 2 * a.slot_world) {
+        const float hi = (float)mx, lo = (float)(mx - (double)hi);
+        a.wmax_slots[tid] = (tid >> 1) == a.slot_rank ? ((tid & 1) ? lo : hi) : 0.0f;
+    }
     if (tid == 0) {
         if (a.wmax) *a.wmax = mx;
         *a.ticket = 0;                                       // ready for the next launch on this stream
@@ -668,18 +676,23 @@ static int sample_launch(PerSampleArgs& a, void* ws, hipStream_t st) {
     return 0;
 }
 
-int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
-                      const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
-                      int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st,
-                      const SamplePassengers* extra) {
-    PerSampleArgs a;
-    memset(&a, 0, sizeof(a));
+static int fill_passengers(PerSampleArgs& a, const SamplePassengers* extra) {
     if (extra && extra->prep) { a.nprep = (DQN_PREP_BLOCKS * 256 + SMP_THREADS - 1) / SMP_THREADS; a.prep = *extra->prep; }
     if (extra && extra->zero) {
         MCTSQ_CHECK(extra->zero_floats % 4 == 0 && ((uintptr_t)extra->zero & 15) == 0 && extra->zero_floats >= 0 &&
                         extra->zero_floats < ((int64_t)1 << 31), "passenger zero-fill: bad buffer");
         a.zero = extra->zero; a.zero_n4 = extra->zero_floats / 4;
     }
+    return 0;
+}
+
+int launch_per_sample(const u64* tree, const double* prio, int64_t cap, int64_t head, int64_t size,
+                      const double* u, int64_t B, double alpha, double beta, int64_t mass_cap, int64_t* idx,
+                      int64_t* phys, float* w, double* wmax, void* ws, const PerGatherArgs* ga, hipStream_t st,
+                      const SamplePassengers* extra) {
+    PerSampleArgs a;
+    memset(&a, 0, sizeof(a));
+    if (fill_passengers(a, extra)) return -1;
     if (per_tree_desc(cap, &a.T)) return -1;
     a.tree = tree; a.prio = prio; a.cap = cap; a.head = head; a.size = size; a.u = u; a.B = B;
     a.alpha = alpha; a.beta = beta; a.shift = per_mass_shift(mass_cap);
@@ -706,14 +719,23 @@ int launch_per_sample_shard(const u64* tree, const double* prio, int64_t cap, in
                             const u64* targets, const int32_t* count, int64_t bcap, double alpha, double beta,
                             int64_t mass_cap, const u64* shard_mass, const int64_t* shard_size, int world,
                             int64_t* idx, int64_t* phys, double* w64, double* wmax, void* ws,
-                            const PerGatherArgs* ga, hipStream_t st) {
+                            const PerGatherArgs* ga, hipStream_t st, const SamplePassengers* extra,
+                            const ShardWeightOut* raw) {
     PerSampleArgs a;
     memset(&a, 0, sizeof(a));
+    if (fill_passengers(a, extra)) return -1;
     if (per_tree_desc(cap, &a.T)) return -1;
     a.tree = tree; a.prio = prio; a.cap = cap; a.head = head; a.size = size; a.targets = targets; a.count = count;
     a.B = bcap; a.alpha = alpha; a.beta = beta; a.shift = per_mass_shift(mass_cap);
     a.shard_mass = shard_mass; a.shard_size = shard_size; a.world = world;
     a.idx_out = idx; a.phys_out = phys; a.w64 = w64; a.wmax = wmax;
+    if (raw) {
+        MCTSQ_CHECK(raw->w_raw && raw->slots && raw->world >= 1 && raw->world <= 64 && raw->rank >= 0 &&
+                        raw->rank < raw->world && wmax && ws && bcap <= SMP_FUSED_NORM_MAX,
+                    "raw-weight output needs the fused maximum (bcap <= %lld rows, a workspace, d_wmax)",
+                    (long long)SMP_FUSED_NORM_MAX);
+        a.w_raw = raw->w_raw; a.wmax_slots = raw->slots; a.slot_world = raw->world; a.slot_rank = raw->rank;
+    }
     if (ga) a.ga = *ga;
     return sample_launch(a, ws, st);
 }

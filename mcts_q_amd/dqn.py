@@ -183,9 +183,12 @@ class PrioritizedReplayBuffer:
     reference pushes do (a pushed entry carries the maximum forward, so it cannot change between
     pushes that are not separated by update_priorities)."""
 
-    def __init__(self, capacity: int, alpha: float = 0.6, device="cuda:0", flush_every: int = 4096):
-        self.capacity, self.alpha = int(capacity), alpha
-        self.dev = DevicePER(self.capacity, alpha=float(alpha), device=device)
+    def __init__(self, capacity: int, alpha: float = 0.6, device="cuda:0", flush_every: int = 4096,
+                 mass_capacity: int | None = None):
+        """mass_capacity: the summed capacity of all shards when this buffer is one rank's shard of a data-parallel
+        replay (DQNModel(process_group=...)); None for a single buffer."""
+        self.capacity, self.alpha, self._mass_capacity = int(capacity), alpha, mass_capacity
+        self.dev = DevicePER(self.capacity, alpha=float(alpha), device=device, mass_capacity=mass_capacity)
         self._pend_rows, self._pend_next, self._pend_a, self._pend_r, self._pend_d = [], [], [], [], []
         self._flush_every = int(flush_every)
 
@@ -253,7 +256,8 @@ class PrioritizedReplayBuffer:
 
     def load_lists(self, buffer, priorities) -> None:
         """Rebuild the device ring from the reference's list form."""
-        self.dev = DevicePER(self.capacity, alpha=float(self.alpha), device=self.dev.device)
+        self.dev = DevicePER(self.capacity, alpha=float(self.alpha), device=self.dev.device,
+                             mass_capacity=self._mass_capacity)
         items = list(buffer)[-self.capacity:]
         prio = np.asarray(list(priorities)[-self.capacity:], dtype=np.float64)
         if not items:
@@ -335,7 +339,9 @@ class DQNModel:
         self.learner.target.flat.copy_(self.learner.policy.flat)
         self.target_net = self._net_cls(*args, device=device, seq_lens=seq_lens, _qnet=self.learner.target).eval()
         self.optimizer = _AdamFacade(self.learner, lr)
-        self.replay_buffer = PrioritizedReplayBuffer(buffer_capacity, device=device)
+        world = self.learner.world
+        self.replay_buffer = PrioritizedReplayBuffer(buffer_capacity, device=device,
+                                                     mass_capacity=buffer_capacity * world if world > 1 else None)
 
     def update(self):
         """One PER-DQN step (dqn_per.py:401-476): None until the buffer holds max(batch_size,
@@ -347,11 +353,8 @@ class DQNModel:
         u = np.random.random_sample(int(self.batch_size))     # the stream np.random.choice draws from (:292)
         if self.learner.world == 1:                           # the whole step is one library call
             self.learner.step(rb.dev, u)
-        else:
-            batch, w, idx, _ = rb.dev.sample_batch(u)
-            abs_td = self.learner.compute_grad(batch, w)
-            self.learner.apply_grad(tau=None)
-            rb.dev.update_priorities(idx, abs_td)
+        else:                                                 # replay shards sampled as one buffer (parallel.py):
+            self.learner.step_sharded(rb.dev, u)              # every rank drew the same u (seeded alike, :368-373)
         return self.learner.loss[0].clone()
 
     def update_target_network(self, tau: float = 0.005) -> None:
@@ -383,8 +386,9 @@ class DQNModel:
         self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
         if "replay_buffer_data" in ckpt:
             data = ckpt["replay_buffer_data"]
-            self.replay_buffer = PrioritizedReplayBuffer(data["capacity"], alpha=data["alpha"],
-                                                         device=self.learner.device)
+            world = self.learner.world
+            self.replay_buffer = PrioritizedReplayBuffer(data["capacity"], alpha=data["alpha"], device=self.learner.device,
+                                                         mass_capacity=data["capacity"] * world if world > 1 else None)
             self.replay_buffer.load_lists(data["buffer"], data["priorities"])
 
 

@@ -28,15 +28,20 @@ class DeviceLearner:
         z = lambda: torch.zeros(n, dtype=torch.float32, device=self.device)
         self.policy = policy if policy is not None else DeviceQNet(spec, self.device)
         self.target = DeviceQNet(spec, self.device)
-        # flat gradient with the loss in the word behind it: data-parallel runs all-reduce both in ONE call
-        self._gradbuf = torch.zeros(n + 16, dtype=torch.float32, device=self.device)
+        self.group = process_group
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self.rank = 0 if process_group is None else torch.distributed.get_rank(process_group)
+        # flat gradient with the loss in the word behind it and, behind the loss block, the exchange slots of the
+        # data-parallel step (two floats per rank: its largest raw importance weight): data-parallel runs all-reduce
+        # the whole block in ONE call
+        nx = -(-2 * self.world // 16) * 16
+        self._gradbuf = torch.zeros(n + 16 + nx, dtype=torch.float32, device=self.device)
         self.grad, self.loss = self._gradbuf[:n], self._gradbuf[n:n + 1]
+        self._exchange = self._gradbuf[n + 16:n + 16 + 2 * self.world]
         self.exp_avg, self.exp_avg_sq = z(), z()
         self.gamma, self.lr, self.betas, self.eps = float(gamma), float(lr), betas, float(eps)
         self.max_grad_norm = float(max_grad_norm)
         self.step_count = 0
-        self.group = process_group
-        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self._ws = None
         self._small = torch.zeros(int(lib.mctsq_optim_workspace_bytes()), dtype=torch.uint8,
                                   device=self.device)                             # grad-norm partials
@@ -101,7 +106,7 @@ class DeviceLearner:
         if B == 0:
             self._gradbuf.zero_()
             if self.world > 1:
-                all_reduce(self._gradbuf, group=self.group)
+                all_reduce(self._gradbuf[:self.spec.n_flat + 16], group=self.group)
             return torch.empty(0, dtype=torch.float32, device=self.device)
         need = lib.check(lib.mctsq_dqn_grad_workspace_bytes(C.byref(self.desc), B))
         if self._ws is None or self._ws.numel() < need:
@@ -121,7 +126,7 @@ class DeviceLearner:
             ptr(self._ws), self._ws.numel(), self._st()))
         self._have_sumsq = single
         if self.world > 1:                      # data-parallel: ONE all-reduce (RCCL) over [gradient | loss]
-            all_reduce(self._gradbuf, group=self.group)
+            all_reduce(self._gradbuf[:self.spec.n_flat + 16], group=self.group)
         return abs_td
 
     # ---- clip_grad_norm_(10) + Adam.step (+ Polyak) (dqn_per.py:471-472, 510-516) ---------------
@@ -185,6 +190,75 @@ class DeviceLearner:
         lib.check(lib.mctsq_per_dqn_step(C.byref(self.desc), C.byref(a), self._st()))
         self._prep_versions = None                          # parameters moved behind the fragments
         self.policy._prep_version = self.target._prep_version = None
+        r._max_dirty = True
+
+    # ---- the same step over W data-parallel ranks: two library calls around the one gradient collective -----------
+    def step_sharded(self, replay, u, tau: float | None = None, beta: float = 0.4, bcap: int | None = None):
+        """One PER-DQN step over the replay shards of all ranks sampled as ONE buffer (parallel.py): `u` = the B global
+        uniforms, identical on every rank; `replay` = this rank's DevicePER shard (mass_capacity = the sum of the
+        shard capacities).  Collectives per step: the all-gather of the (root mass, size) pairs and ONE all-reduce
+        over [gradient | loss | weight-maximum slots]; nothing is read back to the host (the (kept, dropped) counters
+        of a step are looked at one step later).  Works at world == 1 too (same results as step() up to the fp32
+        rounding of the weight division, include/mctsq_hip.h)."""
+        from .parallel import all_gather_rows, draw_capacity
+        u = torch.as_tensor(u, dtype=torch.float64).to(self.device).contiguous()
+        B = int(u.numel())
+        if bcap is None:
+            bcap = draw_capacity(B, self.world)
+        bcap = -(-int(bcap) // 16) * 16
+        d = getattr(self, "_dp", None)
+        if d is None or d["B"] != B or d["bcap"] != bcap or d["replay"] is not replay:
+            need = lib.check(lib.mctsq_per_dqn_step_workspace_bytes(C.byref(self.desc), bcap))
+            ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            a = StepArgs()
+            a.d_ws, a.ws_bytes = ws.data_ptr() + (-ws.data_ptr()) % 256, need
+            a.d_params, a.d_target_params, a.d_grad = ptr(self.policy.flat), ptr(self.target.flat), ptr(self.grad)
+            a.d_m, a.d_v = ptr(self.exp_avg), ptr(self.exp_avg_sq)
+            a.d_prep_policy, a.d_prep_target, a.d_prep_bwd = ptr(self.policy._prep), ptr(self.target._prep), ptr(self._prep_bwd)
+            a.d_loss, a.d_gnorm, a.d_exchange = ptr(self.loss), ptr(self.grad_norm), ptr(self._exchange)
+            a.B, a.bcap, a.world, a.rank = B, bcap, self.world, self.rank
+            count = torch.zeros(2, dtype=torch.int32, device=self.device)
+            draw = torch.empty(bcap, dtype=torch.int32, device=self.device)
+            a.d_count, a.d_draw = ptr(count), ptr(draw)
+            slots = [(torch.zeros(2, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+            d = self._dp = dict(B=B, bcap=bcap, replay=replay, ws=ws, args=a, count=count, draw=draw, slots=slots,
+                                turn=0, pending=None)
+        if d["pending"] is not None:                # counters of the previous step: recorded a whole step ago, no stall
+            host, ev = d["pending"]
+            ev.synchronize()
+            if int(host[1]) != 0:
+                raise MctsqError(f"sharded replay: {int(host[1])} draws of the previous step exceeded this rank's "
+                                 f"provision of {bcap} rows; raise bcap (parallel.draw_capacity)")
+        a, r = d["args"], replay
+        allv = all_gather_rows(r.mass_and_size(reuse=True), self.group)          # collective 1: [W, 2] device words
+        d["allv"] = allv = allv.t().contiguous()                                # masses [W] | sizes [W]
+        a.d_shard_mass, a.d_shard_size = allv.data_ptr(), allv.data_ptr() + 8 * self.world
+        ws = r._ws_for(bcap)
+        a.d_tree, a.d_prio, a.d_stamp = ptr(r.tree), ptr(r.prio), ptr(r.stamp)
+        a.d_states, a.d_next_states, a.d_actions = ptr(r.states), ptr(r.next_states), ptr(r.actions)
+        a.d_rewards, a.d_dones = ptr(r.rewards), ptr(r.dones)
+        a.capacity, a.head, a.size, a.mass_capacity = r.capacity, r.head, r.size, r.mass_capacity
+        a.alpha, a.beta = r.alpha, float(beta)
+        a.d_per_ws, a.per_ws_bytes, a.d_wmax = ptr(ws), ws.numel(), ptr(r.last_local_wmax)
+        a.gamma, a.lr, a.beta1, a.beta2, a.eps = self.gamma, self.lr, self.betas[0], self.betas[1], self.eps
+        a.max_norm, a.tau = self.max_grad_norm, (-1.0 if tau is None else float(tau))
+        self.step_count += 1
+        a.adam_step = self.step_count
+        a.d_u = ptr(u)
+        a.resplit_first = 1
+        st = self._st()
+        lib.check(lib.mctsq_per_dqn_step_begin(C.byref(self.desc), C.byref(a), st))
+        d["turn"] ^= 1
+        host, ev = d["slots"][d["turn"]]
+        host.copy_(d["count"], non_blocking=True)
+        ev.record()
+        d["pending"] = (host, ev)
+        if self.world > 1:                                                       # collective 2 (RCCL): the whole block
+            all_reduce(self._gradbuf, group=self.group)
+        lib.check(lib.mctsq_per_dqn_step_finish(C.byref(self.desc), C.byref(a), st))
+        self._prep_versions = None                          # parameters moved behind the fragments
+        self.policy._prep_version = self.target._prep_version = None
+        self._have_sumsq = False
         r._max_dirty = True
 
     def update_target(self, tau: float = 1.0):

@@ -274,3 +274,63 @@ def config_print(env_config, train_config, mcts_config) -> str:
     str_id = (f"MCTS_Q_{train_config.str_inv}_BS{env_config.scenario}_{env_config.operation}_ep{env_config.eps_len_d}"
               f"_ts{env_config.sim_step}")
     return str_id + mcts_config.get_hyper() + "_rs" + str(train_config.seed_train)
+
+
+# ---- gymnasium / matplotlib helpers of the entry scripts (mctsq_utils.py:542-642) -------------------------------
+# Both libraries are imported inside the functions, so the module (and `from src.mctsq_utils import ...` at the top
+# of mctsq_main*.py) imports where they are absent; calling them without the library raises its ImportError.
+class CallbackVal:
+    """Validation hook of `MCTSQ.learn` (mctsq_utils.py:542-549): the validation environment, the interval in
+    training steps and the statistics lists the agent fills."""
+
+    def __init__(self, env_id, env_kwargs_data_val, val_steps):
+        import gymnasium as gym
+        self.env = gym.make(env_id, dict_input=env_kwargs_data_val, train_or_eval="eval")
+        self.val_steps = val_steps
+        self.stats = {'steps': [], 'cum_rew': []}
+        self.model = None
+
+
+def create_envs(env_id: str, env_kwargs_data: dict, train_config):
+    """(training environment, validation callback, test environment) (mctsq_utils.py:551-575)."""
+    import gymnasium as gym
+    make = lambda split, mode: gym.make(env_id, dict_input=env_kwargs_data[f'env_kwargs_{split}'], train_or_eval=mode)
+    return (make('train', "train"),
+            CallbackVal(env_id, env_kwargs_data['env_kwargs_val'], val_steps=train_config.val_steps),
+            make('test', "eval"))
+
+
+def plot_results(env_config, stats_dict_test: dict, str_id: str) -> None:
+    """Three stacked panels of the test roll-out (prices, operating state + CH4 flow, reward + cumulative reward)
+    saved as plots/<str_id>_plot.png (mctsq_utils.py:577-642).  The last six steps of an episode are the
+    environment's data overhead and are not drawn; rewards are stored in ct and shown in EUR."""
+    import matplotlib
+    matplotlib.use("Agg", force=False)
+    import matplotlib.pyplot as plt
+    print("---Plot and save RL performance on the test set under ./plots/ ...\n")
+    st, cut = stats_dict_test, slice(None, -6)
+    days = (st['steps_stats'] * env_config.sim_step / 86400.0)[cut]
+    fig, axs = plt.subplots(3, 1, figsize=(10, 6), sharex=True, sharey=False)
+
+    def line(ax, key, label, colour=None, scale=1.0, offset=0.0, ylabel=None, loc="upper left"):
+        ax.plot(days, st[key][cut] * scale + offset, *([colour] if colour else []), label=label)
+        if ylabel is not None:
+            ax.set_ylabel(ylabel)
+        ax.legend(loc=loc, fontsize='small')
+
+    line(axs[0], 'el_price_stats', 'El.')
+    line(axs[0], 'gas_price_stats', '(S)NG', 'g', ylabel='El. & (S)NG prices\n [ct/kWh]')
+    line(axs[0].twinx(), 'eua_price_stats', 'EUA', 'k', ylabel='EUA prices [€/t$_{CO2}$]', loc="upper right")
+    line(axs[1], 'Meth_State_stats', 'state', 'b', offset=1.0, ylabel=' ')
+    axs[1].set_yticks([1, 2, 3, 4, 5])
+    axs[1].set_yticklabels(['Standby', 'Cooldown/Off', 'Startup', 'Partial Load', 'Full Load'])
+    axs[1].grid(axis='y', linestyle='dashed')
+    line(axs[1].twinx(), 'Meth_CH4_flow_stats', 'CH$_4$', 'yellowgreen', scale=1000.0,
+         ylabel='CH$_4$ flow rate\n [mmol/s]', loc="upper right")
+    line(axs[2], 'Meth_reward_stats', 'Reward', 'g', scale=0.01, ylabel='Reward [€]')
+    axs[2].set_xlabel('Time [d]')
+    line(axs[2].twinx(), 'Meth_cum_reward_stats', 'Cum. Reward', 'k', scale=0.01, ylabel='Cumulative \n reward [€]',
+         loc="upper right")
+    fig.suptitle(f"{str_id} \n Rew: {np.round(st['Meth_cum_reward_stats'][-7] / 100, 0)} €", fontsize=9)
+    plt.savefig(f'plots/{str_id}_plot.png')
+    plt.close()

@@ -55,6 +55,35 @@ class FakeGymEnv(FakePerEnv):
         self.eps_sim_steps = eps_sim_steps
 
 
+class FakeStdGymEnv:
+    """Stateful stand-in for the non-`_per` environment protocol (/root/reference/env/ptg_gym_env.py: reset(),
+    step(action), get_obs(), meth_state; deep-copied by the search, mctsq_config_mcts.py:168, 243): the same hash
+    walk as FakePerEnv, kept on the object."""
+
+    def __init__(self, seed=0, horizon=1000, eps_sim_steps=8):
+        self._per = FakePerEnv(seed, horizon)
+        self.action_space = _Discrete(5)
+        self.eps_sim_steps = eps_sim_steps
+        self.reset()
+
+    def reset(self):
+        obs, info = self._per.reset()
+        self._sc = info["state_c"]
+        return obs, {}
+
+    @property
+    def meth_state(self):
+        return self._sc["Meth_State"]
+
+    def get_obs(self):
+        return self._sc["obs_norm"]
+
+    def step(self, action):
+        obs, reward, terminated, truncated, info = self._per.step([action, self._sc])
+        self._sc = info.pop("state_c")
+        return obs, reward, terminated, truncated, info
+
+
 class FakeBatchEnv:
     """Vectorised synthetic environment for the batched-environment protocol of treesearch.LockstepMCTS:
     state vector = (hash, t, meth_state, cumulative reward); observations are a counter-based hash of the

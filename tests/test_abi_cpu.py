@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     dll = ctypes.CDLL(_lib.LIB_PATH)
     missing = [n for n in names if not hasattr(dll, n)]
     assert not missing, missing
-    assert dll.mctsq_abi_version() == 4
+    assert dll.mctsq_abi_version() == 5
 
 
 def test_ctypes_table_matches_header():

@@ -29,8 +29,68 @@ def test_shims_export_the_reference_names():
     import src.mctsq_config_train as tr
     import src.mctsq_utils as ut
     assert hasattr(tr, "TrainConfiguration")
-    for n in ("import_market_data", "import_data", "load_data", "Preprocessing", "initial_print", "config_print"):
+    for n in ("import_market_data", "import_data", "load_data", "Preprocessing", "initial_print", "config_print",
+              "CallbackVal", "create_envs", "plot_results"):
         assert hasattr(ut, n), n
+
+
+def test_entry_script_import_blocks_resolve():
+    """f-4 "run unchanged": the `src.*` import lines of the reference's entry scripts, verbatim
+    (/root/reference/mctsq_main_per.py:27-31, /root/reference/mctsq_main.py:23-27), executed in a fresh interpreter
+    with this repository as cwd.  (The gymnasium import two lines above them is the reference's own dependency.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(GOLDEN.rstrip("/").rsplit("/", 1)[0])
+    per_block = """
+from src.mctsq_utils import load_data, initial_print, config_print, create_envs, plot_results
+from src.mctsq_utils import Preprocessing
+from src.mctsq_config_env import EnvConfiguration
+from src.mctsq_config_train import TrainConfiguration
+from src.mctsq_config_mcts_per import MCTSQConfiguration, MCTSQ
+"""
+    std_block = per_block.replace("src.mctsq_config_mcts_per", "src.mctsq_config_mcts")
+    for block in (per_block, std_block):
+        tail = ("import inspect\n"
+                "assert list(inspect.signature(MCTSQ.learn).parameters) == ['self', 'total_timesteps', 'callback']\n"
+                "assert callable(create_envs) and callable(plot_results) and hasattr(MCTSQConfiguration, 'get_hyper')\n"
+                "print('ok', MCTSQ.__module__)\n")
+        out = subprocess.run([sys.executable, "-c", block + tail], capture_output=True, text=True, cwd=root)
+        assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
+    assert "mcts_std" in out.stdout
+
+
+def test_run_id_strings_of_both_flavours(capsys):
+    """MCTSQConfiguration.get_hyper (mctsq_config_mcts_per.py:577-651, mctsq_config_mcts.py:460-532): the `_per`
+    identifier carries the soft-update factor `_ta`, the non-`_per` one does not."""
+    from src.mctsq_config_mcts import MCTSQConfiguration as Std
+    from src.mctsq_config_mcts_per import MCTSQConfiguration as Per
+    vals = dict(iterations=50, c_init=1.25, c_base=19652, maximum_depth=42, learning_rate=0.001, discount_factor=0.99,
+                buffer_size=1000, batch_size=256, hidden_layers=2, hidden_units=128, activation='relu', tau=0.005,
+                seq_length=10, embed_dim=64, price_encoder_type='gru', process_encoder_type='gru',
+                gas_eua_encoder_type='gru')
+    per, std = Per(values=dict(vals)).get_hyper(), Std(values=dict(vals)).get_hyper()
+    assert per == "_it50_pu1.25_pi19652_md42_al0.001_ga0.99_rb1000_bs256_hl2_hu128_afrelu_ta0.005_sq10_ed64_eegru_pegru_gegru"
+    assert std == per.replace("_ta0.005", "")
+    with pytest.raises(ValueError):
+        Std(values=dict(vals)).hyp_print('Softupdate factor')
+
+
+def test_plot_results_writes_the_figure(tmp_path, monkeypatch):
+    """plot_results (mctsq_utils.py:577-642) on a synthetic statistics dict: one PNG under ./plots/."""
+    from src.mctsq_utils import plot_results
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("plots")
+    n = 50
+    rng = np.random.RandomState(0)
+    stats = {k: rng.random_sample(n) for k in ("el_price_stats", "gas_price_stats", "eua_price_stats",
+                                               "Meth_CH4_flow_stats", "Meth_reward_stats", "Meth_cum_reward_stats")}
+    stats["steps_stats"] = np.arange(n, dtype=np.float64)
+    stats["Meth_State_stats"] = rng.randint(0, 5, n).astype(np.float64)
+
+    class EC:
+        sim_step = 600
+    plot_results(EC(), stats, "run_x")
+    assert os.path.getsize(tmp_path / "plots" / "run_x_plot.png") > 10000
 
 
 def test_preprocessing_plumbing_on_synthetic_files(tmp_path):

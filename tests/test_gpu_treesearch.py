@@ -85,6 +85,53 @@ def test_mctsq_learn_predict_save_load(tmp_path):
     assert a1 == a2 and 0 <= a1 < 5
 
 
+def test_non_per_agent_searches_a_deep_copied_environment(tmp_path):
+    """src/mctsq_config_mcts.py flavour (/root/reference/src/mctsq_config_mcts.py:103-185): the search runs on deep
+    copies (the live environment is untouched by predict), the tree equals the per-node restatement driven through
+    the same copies with the same network, learn() pushes ONE transition per step, copies the target network every
+    `target_update` steps and stops at `terminated`."""
+    from mcts_q_amd.synthetic_env import FakeStdGymEnv
+    from src.mctsq_config_mcts import MCTSQ, MCTSQConfiguration
+    cfg = dict(MCFG, target_update=7, learning_starts=32, iterations=20)
+    env = FakeStdGymEnv(3, horizon=60)
+    agent = MCTSQ(env, seed=5, config=MCTSQConfiguration(values=cfg))
+    assert agent.dqn.policy_net.spec.flavor == "std" and agent.dqn.el_input_dim == 3
+    before = dict(env._sc)
+    random.seed(2)
+    a = agent.predict(env)
+    assert env._sc == before and 0 <= a < 5 and agent._search.n == 0
+    # the same search, node by node, over state records that carry their environment copy
+    import copy
+    from mcts_q_amd import mcts_std
+
+    class CopyEnv:                                            # `_per` protocol on top of the deep copies
+        def step(self, arg):
+            return mcts_std._step_copy(0, arg[0], arg[1])
+
+    def q_fn(p, q, g):
+        return agent.dqn.policy_net(p, q, g)
+    random.seed(2)
+    ref = mcts_ref.RefSearch(q_fn, CopyEnv(), 20, 42, 19652, 1.25, random)
+    assert ref.predict(mcts_std._record(copy.deepcopy(env)), "eval") == a
+
+    class Cb:
+        env, val_steps = FakeStdGymEnv(99, eps_sim_steps=2), 30
+    tgt0 = agent.dqn.target_net.state_dict()["fc_layers.0.weight"].copy()
+    agent.learn(100, Cb())
+    assert agent.step == 59 and len(agent.dqn.replay_buffer) == 60          # broke at `terminated`, one push per step
+    pol, tgt = agent.dqn.policy_net.state_dict(), agent.dqn.target_net.state_dict()
+    assert not np.array_equal(tgt["fc_layers.0.weight"], tgt0)             # hard copies happened (steps 7, 14, ...)
+    assert not np.array_equal(tgt["fc_layers.0.weight"], pol["fc_layers.0.weight"])   # ... and updates after the last one
+    path = os.path.join(tmp_path, "std.pt")
+    agent.save(path)
+    other = MCTSQ(FakeStdGymEnv(1), seed=9, config=MCTSQConfiguration(values=cfg))
+    other.load(path)
+    e2 = FakeStdGymEnv(8)
+    random.seed(4); a1 = agent.predict(e2)
+    random.seed(4); a2 = other.predict(e2)
+    assert a1 == a2
+
+
 def test_lockstep_agent_many_trees_one_learner():
     from mcts_q_amd.dqn import DQNModel
     from mcts_q_amd.mcts import LockstepAgent
