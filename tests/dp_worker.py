@@ -59,7 +59,7 @@ def main():
         L.step_sharded(buf, u_all[i], tau=TAU)
         torch.cuda.synchronize()
         d = L._dp
-        ws_idx = None
+        rec[f"masses{i}"] = d["allv"].cpu().numpy()           # [masses W | sizes W] the step sampled with
         rec[f"count{i}"] = d["count"].cpu().numpy()
         rec[f"draw{i}"] = d["draw"].cpu().numpy()
         rec[f"exchange{i}"] = L._exchange.cpu().numpy().copy()

@@ -28,6 +28,17 @@ def _close(a, b, rel):
     return float(np.abs(a - b).max()) <= rel * scale
 
 
+def _params_close(p, p_ref, t, t_ref, grad0, steps, lr=1e-3, tau=0.005):
+    """Adam's first steps move a weight by ~lr whatever the size of its gradient, so where the gradient is rounding
+    noise (|g| far below the largest entry) a last-bit difference decides the direction: there the bound is the
+    distance Adam can travel; where the gradient is significant the parameters must agree to fp32 rounding of lr."""
+    clear = np.abs(grad0) > 1e-3 * np.abs(grad0).max()
+    dp = np.abs(p - p_ref)
+    assert clear.sum() > 1000 and float(dp[clear].max()) <= 1e-3 * lr * steps, float(dp[clear].max())
+    assert float(dp.max()) <= 2.0 * lr * steps
+    assert float(np.abs(t - t_ref).max()) <= tau * steps * max(float(dp.max()), 1e-7) * 1.01
+
+
 def _single_process_reference():
     import dp_worker as W
     from mcts_q_amd import NetSpec
@@ -47,10 +58,10 @@ def _single_process_reference():
     out = []
     for i in range(W.STEPS):
         idx, _, w = buf.sample_indices(u_all[i])            # what the step is about to draw (sampling changes nothing)
-        wmax = float(buf.last_local_wmax.item())
+        wmax, mass = float(buf.last_local_wmax.item()), int(buf.total_mass().item())
         L.step(buf, u_all[i], tau=W.TAU)
         torch.cuda.synchronize()
-        out.append(dict(idx=idx.cpu().numpy(), w=w.cpu().numpy(), wmax=wmax, loss=float(L.loss.item()),
+        out.append(dict(idx=idx.cpu().numpy(), w=w.cpu().numpy(), wmax=wmax, mass=mass, loss=float(L.loss.item()),
                         gnorm=float(L.grad_norm.item()), prio=buf.logical_priorities().copy(),
                         grad=L.grad.cpu().numpy().copy()))
     fin = dict(params=L.policy.flat.cpu().numpy(), target=L.target.flat.cpu().numpy(), m=L.exp_avg.cpu().numpy(),
@@ -88,9 +99,16 @@ def test_two_ranks_on_the_real_kernels_equal_the_single_process_step(tmp_path):
             assert np.array_equal(d[:kept], mine) and (d[kept:] == -1).all()
             served[d[:kept]] += 1
         assert (served == 1).all()
+        ms = ranks[0][f"masses{i}"]
+        assert np.array_equal(ms, ranks[1][f"masses{i}"]) and ms[1].tolist() == list(W.SIZES)
+        # steps 0 and 1 sample from bit-identical priorities (the parameters first differ, by rounding, after step 0,
+        # so the |td| written by step 1 differ in the last bits): exact there, close afterwards
+        exact = i <= 1
+        msum = int(ms[0, 0]) + int(ms[0, 1])
+        assert msum == ref["mass"] if exact else abs(msum - ref["mass"]) <= 1e-6 * ref["mass"], (i, ms, ref["mass"])
         ex = ranks[0][f"exchange{i}"].astype(np.float64)
         gmax = max(ex[0] + ex[1], ex[2] + ex[3])
-        assert abs(gmax - ref["wmax"]) <= 1e-13 * ref["wmax"]
+        assert abs(gmax - ref["wmax"]) <= (1e-13 if exact else 1e-6) * ref["wmax"], (i, gmax, ref["wmax"])
         prio = np.concatenate([z[f"prio{i}"] for z in ranks])
         if i == 0:
             assert np.array_equal(prio, ref["prio"])            # same parameters, row-wise forward: same |td| bits
@@ -100,10 +118,7 @@ def test_two_ranks_on_the_real_kernels_equal_the_single_process_step(tmp_path):
         assert abs(float(ranks[0][f"gnorm{i}"][0]) - ref["gnorm"]) <= 1e-5 * ref["gnorm"]
         assert _close(ranks[0][f"grad{i}"], ref["grad"], 1e-5 if i == 0 else 1e-4)
     assert _close(ranks[0]["m"], fin["m"], 1e-5) and _close(ranks[0]["v"], fin["v"], 1e-5)
-    # Adam's first steps move every weight by ~lr whatever the gradient's size, so rounding-level gradient
-    # differences show up in the parameters as a small fraction of lr
-    assert float(np.abs(ranks[0]["params"] - fin["params"]).max()) <= 2e-5
-    assert float(np.abs(ranks[0]["target"] - fin["target"]).max()) <= 2e-7
+    _params_close(ranks[0]["params"], fin["params"], ranks[0]["target"], fin["target"], steps[0]["grad"], W.STEPS)
 
 
 def test_begin_finish_at_world_one_equals_the_one_call_step():
@@ -127,8 +142,10 @@ def test_begin_finish_at_world_one_equals_the_one_call_step():
                 L.step_sharded(buf, u_all[i], tau=W.TAU)
                 assert L._dp["count"].tolist() == [128, 0]
             pr.append(buf.logical_priorities().copy())
-        runs.append((L.policy.flat.cpu().numpy(), L.target.flat.cpu().numpy(), pr, float(L.loss.item())))
-    (p1, t1, pr1, l1), (p2, t2, pr2, l2) = runs
+            if i == 0:
+                g0 = L.grad.cpu().numpy().copy()
+        runs.append((L.policy.flat.cpu().numpy(), L.target.flat.cpu().numpy(), pr, float(L.loss.item()), g0))
+    (p1, t1, pr1, l1, g1), (p2, t2, pr2, l2, _) = runs
     assert np.array_equal(pr1[0], pr2[0])
     assert _close(pr2[2], pr1[2], 2e-5) and abs(l1 - l2) <= 1e-5 * abs(l1)
-    assert float(np.abs(p1 - p2).max()) <= 2e-5 and float(np.abs(t1 - t2).max()) <= 2e-7
+    _params_close(p2, p1, t2, t1, g1, 3)

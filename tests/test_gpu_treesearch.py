@@ -116,12 +116,13 @@ def test_non_per_agent_searches_a_deep_copied_environment(tmp_path):
 
     class Cb:
         env, val_steps = FakeStdGymEnv(99, eps_sim_steps=2), 30
-    tgt0 = agent.dqn.target_net.state_dict()["fc_layers.0.weight"].copy()
+    tgt0 = agent.dqn.target_net.state_dict()["fc_layers.0.weight"].cpu().numpy().copy()
     agent.learn(100, Cb())
     assert agent.step == 59 and len(agent.dqn.replay_buffer) == 60          # broke at `terminated`, one push per step
-    pol, tgt = agent.dqn.policy_net.state_dict(), agent.dqn.target_net.state_dict()
-    assert not np.array_equal(tgt["fc_layers.0.weight"], tgt0)             # hard copies happened (steps 7, 14, ...)
-    assert not np.array_equal(tgt["fc_layers.0.weight"], pol["fc_layers.0.weight"])   # ... and updates after the last one
+    pol = agent.dqn.policy_net.state_dict()["fc_layers.0.weight"].cpu().numpy().copy()
+    tgt = agent.dqn.target_net.state_dict()["fc_layers.0.weight"].cpu().numpy().copy()
+    assert not np.array_equal(tgt, tgt0)                                  # hard copies happened (steps 7, 14, ...)
+    assert not np.array_equal(tgt, pol)                                   # ... and updates after the last one
     path = os.path.join(tmp_path, "std.pt")
     agent.save(path)
     other = MCTSQ(FakeStdGymEnv(1), seed=9, config=MCTSQConfiguration(values=cfg))

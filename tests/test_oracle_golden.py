@@ -51,6 +51,26 @@ def test_numpy_forward_matches_reference(path):
     np.testing.assert_allclose(pr, z["prior"], rtol=1e-5, atol=1e-7)
 
 
+TRAINED_FILES = sorted(glob.glob(os.path.join(GOLDEN, "trained_*.npz")))
+
+
+@pytest.mark.parametrize("path", TRAINED_FILES, ids=[os.path.basename(p)[8:-4] for p in TRAINED_FILES])
+def test_oracle_forward_on_trained_weights(path):
+    """The oracle against the reference's forward (fp32 and module.double()) on weights the reference trained for
+    300 updates (tests/golden/gen_golden_r3.py): the fp64 restatement reproduces the reference's fp64 evaluation to
+    ~1e-12, the torch restatement its fp32 Q bit for bit."""
+    z, cfg = load_case(path)
+    sd = {k[3:]: z[k] for k in z.files if k.startswith("sd/")}
+    assert len(TRAINED_FILES) == 3 and max(cfg["drift"].values()) > 1.0      # the weights did move
+    q64 = qnet_numpy.q_forward(sd, cfg, z["price"], z["process"], z["gas"], np.float64)
+    scale = np.abs(z["Q64"]).max()
+    assert np.abs(q64 - z["Q64"]).max() <= 1e-10 * scale
+    with torch.no_grad():
+        q32 = torch_ref.RefQNet.from_state_dict(cfg, sd)(*(torch.from_numpy(z[k]) for k in ("price", "process", "gas")))
+    assert np.array_equal(q32.numpy(), z["Q"])
+    assert np.array_equal(q64.argmax(1), z["argmax"])
+
+
 @pytest.mark.parametrize("path", QNET_FILES, ids=[os.path.basename(p)[5:-4] for p in QNET_FILES])
 def test_torch_ref_forward_and_grads_match_reference(path):
     z, cfg = load_case(path)
