@@ -479,23 +479,65 @@ __global__ __launch_bounds__(256) void per_update_mark_kernel(int32_t* __restric
     atomicMax(&stamp[phys], (int32_t)i);
 }
 
-__global__ __launch_bounds__(256) void per_update_kernel(u64* __restrict__ tree, PerTree T,
-                                                         double* __restrict__ prio, int32_t* __restrict__ stamp,
-                                                         int64_t cap, int64_t head, int64_t size,
-                                                         const int64_t* __restrict__ idx,
-                                                         const float* __restrict__ newp, int64_t B,
-                                                         double alpha, int shift) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= B) return;
-    const int64_t li = idx[i];
-    if (li < 0 || li >= size) return;
-    int64_t phys = head + li;
-    if (phys >= cap) phys -= cap;
-    if (stamp[phys] != (int32_t)i) return;
-    stamp[phys] = -1;
-    const double p = (double)newp[i];
-    prio[phys] = p;
-    set_leaf(tree, T, phys, mctsq_mass(p, alpha, shift));
+// Bulk apply (batches above UPD_FUSED_MAX: replay set-up, checkpoint import).  Every entry that won its slot writes the
+// leaf and owes its mass delta to one node per upper level.  With one global atomic per level and entry, a million
+// entries queue up on the few words of the two top levels (12 ms per million, measured): a workgroup therefore sums
+// its entries' deltas for those two levels in LDS and issues one global add per node it touched; on the
+// levels below, a wave whose lanes all name the same node (consecutive indices) adds one wave sum instead of 64.
+constexpr int UPD_BULK_THREADS = 1024, UPD_BULK_PER_THREAD = 8;
+__global__ __launch_bounds__(UPD_BULK_THREADS) void per_update_kernel(u64* __restrict__ tree, PerTree T,
+                                                                      double* __restrict__ prio, int32_t* __restrict__ stamp,
+                                                                      int64_t cap, int64_t head, int64_t size,
+                                                                      const int64_t* __restrict__ idx,
+                                                                      const float* __restrict__ newp, int64_t B,
+                                                                      double alpha, int shift, int per_thread) {
+    __shared__ u64 s_top[64], s_l2[SMP_L2MAX];
+    const int tid = threadIdx.x, lane = tid & 63, top = T.nlev - 1;
+    const bool lds_top = top >= 1, lds_l2 = top >= 2 && T.cnt[top - 1] <= SMP_L2MAX;
+    if (tid < 64) s_top[tid] = 0;
+    if (lds_l2) for (int i = tid; i < (int)T.cnt[top - 1]; i += UPD_BULK_THREADS) s_l2[i] = 0;
+    __syncthreads();
+    for (int k = 0; k < per_thread; ++k) {
+        const int64_t i = ((int64_t)blockIdx.x * per_thread + k) * UPD_BULK_THREADS + tid;
+        u64 delta = 0;
+        int64_t phys = 0;
+        if (i < B) {
+            const int64_t li = idx[i];
+            if (li >= 0 && li < size) {
+                phys = head + li;
+                if (phys >= cap) phys -= cap;
+                if (stamp[phys] == (int32_t)i) {
+                    stamp[phys] = -1;
+                    const double p = (double)newp[i];
+                    prio[phys] = p;
+                    const u64 m = mctsq_mass(p, alpha, shift);
+                    const u64 old = tree[T.off[0] + phys];
+                    tree[T.off[0] + phys] = m;
+                    delta = m - old;                         // wraps for decreases; sums stay exact
+                }
+            }
+        }
+        int64_t node = phys;
+        for (int l = 1; l <= top; ++l) {                     // wave-uniform trip count
+            node >>= 6;
+            if (l == top && lds_top) { if (delta) atomicAdd(&s_top[node], delta); continue; }
+            if (l == top - 1 && lds_l2) { if (delta) atomicAdd(&s_l2[node], delta); continue; }
+            // one node for the whole wave (lanes without a delta go along with 0)?  then one add of the wave's sum
+            const int64_t first = __shfl(node, __ffsll((long long)__ballot(delta != 0)) - 1, 64);
+            const bool same = __ballot(delta != 0 && node != first) == 0;
+            if (same) {
+                const u64 tot = readlane_u64(wave_incl_scan(delta, lane), 63);
+                if (lane == 0 && tot != 0) atomicAdd(&tree[T.off[l] + first], tot);
+            } else if (delta) {
+                atomicAdd(&tree[T.off[l] + node], delta);
+            }
+        }
+    }
+    __syncthreads();
+    if (lds_top && tid < (int)T.cnt[top] && s_top[tid] != 0) atomicAdd(&tree[T.off[top] + tid], s_top[tid]);
+    if (lds_l2)
+        for (int i = tid; i < (int)T.cnt[top - 1]; i += UPD_BULK_THREADS)
+            if (s_l2[i] != 0) atomicAdd(&tree[T.off[top - 1] + i], s_l2[i]);
 }
 
 // The whole update in ONE workgroup for batches up to UPD_FUSED_MAX (the training batch).  "Last duplicate wins"
@@ -573,17 +615,58 @@ __global__ __launch_bounds__(1024) void per_update_fused_kernel(u64* __restrict_
             if (s_l2[i] != 0) atomicAdd(&tree[T.off[top - 1] + i], s_l2[i]);
 }
 
-__global__ __launch_bounds__(256) void per_push_kernel(u64* __restrict__ tree, PerTree T,
-                                                       double* __restrict__ prio, int64_t cap,
-                                                       int64_t first_slot, int64_t K,
-                                                       const double* __restrict__ maxprio, double alpha,
-                                                       int shift) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= K) return;
-    const int64_t phys = (first_slot + i) % cap;
+// Push: the K new entries are one run of ring slots (two when it wraps) and all carry the SAME mass (the current
+// maximum priority), so nothing needs an atomic on the lower levels: one workgroup owns one 4096-slot span (= 64
+// level-1 nodes = one level-2 node), writes the new leaves, recomputes every level-1 node the run touches from its 64
+// children (new mass inside the run, stored leaf outside), its level-2 node from the 64 level-1 values, and hands the
+// level-2 delta to the (few-word) levels above with one atomic each.  Spans the run does not touch leave at once.
+// (One global atomic per level and entry queued a million pushes on the root word: 12 ms per million, measured.)
+constexpr int PUSH_THREADS = 1024, PUSH_SPAN = 4096;
+__global__ __launch_bounds__(PUSH_THREADS) void per_push_kernel(u64* __restrict__ tree, PerTree T,
+                                                                double* __restrict__ prio, int64_t cap,
+                                                                int64_t first_slot, int64_t K,
+                                                                const double* __restrict__ maxprio, double alpha,
+                                                                int shift) {
+    __shared__ u64 s_l1[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, top = T.nlev - 1;
+    const int64_t span0 = (int64_t)blockIdx.x * PUSH_SPAN;
+    // does the run [first_slot, first_slot + K) mod cap meet this span?  (two plain intervals)
+    const int64_t e1 = first_slot + K <= cap ? first_slot + K : cap, e2 = first_slot + K - cap;   // [first, e1) and [0, e2)
+    const int64_t hi = span0 + PUSH_SPAN < cap ? span0 + PUSH_SPAN : cap;
+    const bool meets = (first_slot < hi && e1 > span0) || (e2 > span0);
+    if (!meets) return;
     const double p = *maxprio;
-    prio[phys] = p;
-    set_leaf(tree, T, phys, mctsq_mass(p, alpha, shift));
+    const u64 m = mctsq_mass(p, alpha, shift);
+    for (int j = wv; j < 64; j += PUSH_THREADS / 64) {           // level-1 node j of the span: leaves [64 j, 64 j + 64)
+        const int64_t leaf = span0 + (int64_t)j * 64 + lane;
+        const bool in = leaf < cap && ((leaf >= first_slot && leaf < e1) || leaf < e2);
+        const bool any = __ballot(in) != 0;                      // wave-uniform
+        u64 v = 0;
+        if (any) {
+            if (in) { tree[T.off[0] + leaf] = m; prio[leaf] = p; v = m; }
+            else if (leaf < cap) v = tree[T.off[0] + leaf];
+            v = readlane_u64(wave_incl_scan(v, lane), 63);
+            if (top >= 1 && lane == 0) tree[T.off[1] + (span0 >> 6) + j] = v;
+        } else if (top >= 2) {                                   // untouched node: its stored value enters the level-2 sum
+            const int64_t n1 = (span0 >> 6) + j;
+            v = n1 < T.cnt[1] ? tree[T.off[1] + n1] : 0;
+        }
+        if (lane == 0) s_l1[j] = v;
+    }
+    if (top < 2) return;
+    __syncthreads();
+    if (wv == 0) {
+        const u64 tot = readlane_u64(wave_incl_scan(s_l1[lane], lane), 63);
+        if (lane == 0) {
+            const int64_t n2 = span0 >> 12;
+            const u64 old = tree[T.off[2] + n2];
+            tree[T.off[2] + n2] = tot;
+            const u64 delta = tot - old;
+            int64_t node = n2;
+            if (delta)
+                for (int l = 3; l <= top; ++l) { node >>= 6; atomicAdd(&tree[T.off[l] + node], delta); }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ max over live priorities
@@ -782,8 +865,13 @@ int launch_per_update(u64* tree, double* prio, int32_t* stamp, int64_t cap, int6
     } else {
         const dim3 grid((unsigned)((B + 255) / 256));
         hipLaunchKernelGGL(per_update_mark_kernel, grid, dim3(256), 0, st, stamp, cap, head, size, idx, B);
-        hipLaunchKernelGGL(per_update_kernel, grid, dim3(256), 0, st, tree, T, prio, stamp, cap, head, size, idx, newp,
-                           B, alpha, shift);
+        // entries per thread: one while the launch still leaves CUs idle, up to UPD_BULK_PER_THREAD for the big batches
+        // (fewer workgroups = fewer flushes of the LDS sums)
+        int per_thread = (int)(B / ((int64_t)UPD_BULK_THREADS * 256));
+        per_thread = per_thread < 1 ? 1 : (per_thread > UPD_BULK_PER_THREAD ? UPD_BULK_PER_THREAD : per_thread);
+        const int64_t per_block = (int64_t)UPD_BULK_THREADS * per_thread;
+        hipLaunchKernelGGL(per_update_kernel, dim3((unsigned)((B + per_block - 1) / per_block)), dim3(UPD_BULK_THREADS), 0, st,
+                           tree, T, prio, stamp, cap, head, size, idx, newp, B, alpha, shift, per_thread);
     }
     MCTSQ_HIP(hipGetLastError());
     return 0;
@@ -794,8 +882,8 @@ int launch_per_push(u64* tree, double* prio, const double* maxprio, int64_t cap,
     PerTree T;
     if (per_tree_desc(cap, &T)) return -1;
     const int64_t first = (head + size) % cap;
-    hipLaunchKernelGGL(per_push_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, tree, T, prio, cap,
-                       first, K, maxprio, alpha, per_mass_shift(mass_cap));
+    hipLaunchKernelGGL(per_push_kernel, dim3((unsigned)((cap + PUSH_SPAN - 1) / PUSH_SPAN)), dim3(PUSH_THREADS), 0, st, tree,
+                       T, prio, cap, first, K, maxprio, alpha, per_mass_shift(mass_cap));
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -89,6 +89,67 @@ def test_masses_and_tree_bit_exact_vs_oracle():
     assert int(tree[5056 + 128:5056 + 128 + 2].sum()) == int(m_or.sum())
 
 
+def _check_tree(buf, prio_phys):
+    """Every level of the device tree against sums recomputed on the host from the expected leaf masses."""
+    from mcts_q_amd._lib import lib
+    cap = buf.capacity
+    m, _ = per_numpy.masses(np.asarray(prio_phys, dtype=np.float64), buf.alpha, lib.mctsq_per_mass_shift(buf.mass_capacity))
+    tree = buf.tree.cpu().numpy().view(np.uint64)
+    level, off = m.astype(np.uint64), 0
+    while True:
+        pad = -(-len(level) // 64) * 64
+        assert np.array_equal(tree[off:off + len(level)], level), f"level at word {off}"
+        assert not tree[off + len(level):off + pad].any()
+        if len(level) <= 64:
+            break
+        level = np.add.reduceat(np.concatenate([level, np.zeros(pad - len(level), dtype=np.uint64)]), np.arange(0, pad, 64))
+        off += pad
+    assert off + pad == len(tree)
+
+
+@pytest.mark.parametrize("cap", [50, 3000, 70_000, 300_000])
+def test_tree_levels_after_wrapped_pushes_and_bulk_updates(cap):
+    """Push (one workgroup per 4096-slot span rebuilds the nodes the run touches, no per-entry atomics) and the bulk
+    priority update (LDS pre-sums for the two top levels): trees of one to four levels, runs that start and end inside
+    a span, wrap around the ring, cover it whole; every level equals the sums of the expected leaves, and the sampled
+    indices equal the oracle's."""
+    from mcts_q_amd.per import DevicePER
+    rng = np.random.RandomState(cap)
+    buf = DevicePER(cap)
+    prio = np.zeros(cap)                                   # by PHYSICAL slot
+    head, size = 0, 0
+    for K in (max(1, cap // 3), max(1, cap // 2) + 7, min(cap, 4097), 1, cap):
+        K = min(K, cap)
+        rows = torch.zeros(K, 91, device="cuda")
+        buf.push_rows(rows, torch.zeros(K), torch.zeros(K), rows, torch.zeros(K))
+        live = prio[(head + np.arange(size)) % cap]
+        newp = live.max() if size else 1.0                 # max(priorities, default=1.0) (dqn_per.py:265)
+        start = (head + size) % cap
+        prio[(start + np.arange(K)) % cap] = newp
+        over = max(0, size + K - cap)
+        size, head = min(size + K, cap), (head + over) % cap
+        assert (buf.head, buf.size) == (head, size)
+        _check_tree(buf, prio)
+        # bulk update of a random subset with duplicates (> 2048 entries where the ring is big enough)
+        n_upd = min(size, 5000) + 3
+        li = rng.randint(0, size, n_upd)
+        pv = (np.abs(rng.standard_normal(n_upd)) * 2).astype(np.float32)
+        pv[::11] = 0.0
+        buf.update_priorities(li, pv)
+        for i in range(n_upd):                              # sequential semantics: the last duplicate wins
+            prio[(head + li[i]) % cap] = float(pv[i])
+        _check_tree(buf, prio)
+    # consecutive indices (one level-1 node per wave: the wave-sum path) over the whole ring
+    pv = np.abs(rng.standard_normal(size)).astype(np.float32)
+    buf.update_priorities(np.arange(size), pv)
+    prio[(head + np.arange(size)) % cap] = pv.astype(np.float64)
+    _check_tree(buf, prio)
+    u = rng.random_sample(64)
+    idx, _, w = buf.sample_indices(u)
+    idx_or, w_or, _ = per_numpy.fixed_point_sample(prio[(head + np.arange(size)) % cap], u, capacity=cap)
+    assert np.array_equal(idx.cpu().numpy(), idx_or) and np.array_equal(w.cpu().numpy(), w_or)
+
+
 def test_large_buffer_statistics_and_roundtrip():
     """BASELINE config 3 size (N = 1M, B = 1024): indices equal the oracle's exactly; empirical
     sampling frequencies follow p_i; update -> sample round trip moves mass as expected."""
