@@ -131,22 +131,133 @@ def profile_numbers():
     return out
 
 
-BF16_MATRIX_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md
+BF16_MATRIX_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md (fp16 MFMA: same rate)
+SPLIT2_FP16_CEILING = BF16_MATRIX_PEAK_TFLOPS / 3.0      # two-way fp16 split: three products per fp32 product = 833
+SPLIT3_BF16_CEILING = BF16_MATRIX_PEAK_TFLOPS / 6.0      # three-way bf16 split: six products = 417
+
+
+def flop_classes(spec):
+    """Forward FLOPs per leaf by the matrix instruction that EXECUTES them:
+    'fp16x3'  two-way fp16 split (GRU recurrence, the conv encoder's second convolution, the transformer FFN),
+    'bf16x6'  exact three-way bf16 split (attention in_proj / out_proj, the 192-128-128-A head),
+    'fp32'    v_mfma_f32_16x16x4_f32 and vector arithmetic (input projections, conv1, embedding, per-head attention,
+              the gas/EUA MLP, pooling)."""
+    c = {"fp16x3": 0, "bf16x6": 0, "fp32": 0}
+    for kind, S, F in zip((spec.price, spec.process, spec.gas), spec.seq, spec.feat_dims):
+        if kind == "gru":
+            c["fp16x3"] += S * 2 * 192 * 64
+            c["fp32"] += S * 2 * 192 * F + S * 4 * 64
+        elif kind == "conv":
+            c["fp16x3"] += S * 2 * 64 * 64 * 3
+            c["fp32"] += S * 2 * 64 * F * 3 + S * 4 * 64
+        elif kind == "mlp":
+            c["fp32"] += 2 * 64 * 3 * F + 2 * 64 * 64
+        elif kind == "transformer":
+            c["fp16x3"] += S * 2 * (4 * 64 * 2048)
+            c["bf16x6"] += S * 2 * (2 * 192 * 64 + 2 * 64 * 64)
+            c["fp32"] += S * (2 * 64 * F + 2 * 4 * S * 64)
+    enc, head = forward_flops(spec)
+    assert sum(c.values()) == enc
+    shipped_head = spec.hidden_layers == 2 and spec.hidden_units == 128
+    c["bf16x6" if shipped_head else "fp32"] += head
+    return c
 
 
 def executed_pipe_peak(spec):
-    """Ceiling of the instructions the kernel actually issues, in fp32-equivalent TFLOP/s: the recurrent products run
-    as THREE fp16 MFMAs per fp32 product (two-way split: 2500 / 3 = 833), the head as SIX bf16 MFMAs (three-way split:
-    2500 / 6 = 417), the input projections as fp32 MFMA (157.3); the shares are weighted by the time each would take
-    at its own peak.  Returns (ceiling, share of the FLOPs on the 16-bit matrix instructions)."""
-    enc, head = forward_flops(spec)
-    gru = [(S, F) for kind, S, F in zip((spec.price, spec.process, spec.gas), spec.seq, spec.feat_dims) if kind == "gru"]
-    fp32 = sum(S * 2 * 192 * F for S, F in gru)
-    rec = sum(S * 2 * 192 * 64 for S, F in gru)
-    total = enc + head
-    six = total - fp32 - rec                      # head (and whatever else the encoders multiply: none for gru/gru/gru)
-    t = rec / (BF16_MATRIX_PEAK_TFLOPS / 3.0) + six / (BF16_MATRIX_PEAK_TFLOPS / 6.0) + fp32 / FP32_MATRIX_PEAK_TFLOPS
-    return total / t, (rec + six) / total
+    """Ceiling of the instructions the forward actually issues, in fp32-equivalent TFLOP/s: the classes of
+    flop_classes() weighted by the time each would take at its own peak (833 / 417 / 157.3).  Returns (ceiling, share
+    of the FLOPs on the 16-bit matrix instructions)."""
+    c = flop_classes(spec)
+    total = sum(c.values())
+    t = c["fp16x3"] / SPLIT2_FP16_CEILING + c["bf16x6"] / SPLIT3_BF16_CEILING + c["fp32"] / FP32_MATRIX_PEAK_TFLOPS
+    return total / t, (c["fp16x3"] + c["bf16x6"]) / total
+
+
+DOMINANT_KERNEL = {"gru/gru/gru": "gru3_head_fwd_kernel<false>", "conv/conv/mlp": "conv_enc_fwd_kernel",
+                   "transformer/transformer/gru": "tf_ffn_pair_kernel"}
+TRAIN_DOMINANT = {"gru/gru/gru": "gru3_head_fwd_pair_kernel", "conv/conv/mlp": "conv_enc_bwd_kernel",
+                  "transformer/transformer/gru": "tf_ffn_bwd_kernel"}
+
+
+def other_configs(args, dev, buf, settle_fn, steps, warmup):
+    """The BASELINE configurations beside the headline one, each on one GPU (rank 0): forward of conv/conv/mlp at 4096
+    leaves (config 1's network at config 2's batch) and of transformer/transformer/gru at 16384 leaves (config 4), and
+    one PER-DQN step each for conv and transformer at B = 1024 over the 1M-entry replay (config 3's step on the other
+    encoder families).  Fractions are quoted against the fp32-MFMA peak on ALGORITHMIC FLOPs (can exceed 1 for split
+    16-bit execution: labelled as such, not a roofline fraction) and against the executed-pipe ceiling (the roofline
+    fraction proper)."""
+    from mcts_q_amd import NetSpec
+    from mcts_q_amd.hipevents import HipEvent
+    from mcts_q_amd.learner import DeviceLearner
+    from mcts_q_amd.qnet import DeviceQNet
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = []
+    for combo, B, do_train in (("conv/conv/mlp", 4096, True), ("transformer/transformer/gru", 16384, True)):
+        pe, pr, ga = combo.split("/")
+        cfg = dict(price=pe, process=pr, gas=ga, act="relu", flavor="per")
+        spec = NetSpec.from_cfg(cfg)
+        _, sd = seeded_net(cfg)
+        net = DeviceQNet(spec, dev).load_state_dict(sd)
+        g = torch.Generator().manual_seed(7)
+        x = [torch.rand(B, 25, 1, generator=g).to(dev), torch.rand(B, 10, 6, generator=g).to(dev),
+             torch.rand(B, 3, 2, generator=g).to(dev)]
+        o = net(*x)
+        t_end = time.perf_counter() + args.settle_ms * 1e-3        # clock settle under THIS kernel mix
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                net(*x, out=o)
+            torch.cuda.synchronize()
+        n = max(10, min(steps, 50)) if B >= 16384 else max(20, min(steps, 200))
+        for _ in range(max(2, warmup // 4)):
+            net(*x, out=o)
+        e0, e1 = HipEvent(), HipEvent()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(n):
+            net(*x, out=o)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_ms(e1) / n
+        enc_fl, head_fl = forward_flops(spec)
+        flops = (enc_fl + head_fl) * B
+        ach = flops / (ms * 1e-3) / 1e12
+        ceil, share = executed_pipe_peak(spec)
+        rec = {"workload": f"{combo} leaf evaluation, {B} leaves", "encoders": combo, "batch": B, "steps": n,
+               "ms_per_forward": ms, "value": B / (ms * 1e-3), "unit": "leaf evals/s",
+               "dominant_kernel": DOMINANT_KERNEL[combo], "flops_per_leaf": enc_fl + head_fl, "flops": flops,
+               "achieved": ach, "achieved_unit": "TFLOP/s (algorithmic fp32 FLOPs)",
+               "executed_pipe_peak": ceil, "frac_executed_pipe": ach / ceil, "split_16bit_share_of_flops": share,
+               "algorithmic_over_fp32_mfma_peak": ach / FP32_MATRIX_PEAK_TFLOPS,
+               "flop_classes_per_leaf": flop_classes(spec),
+               "hbm_GBs_algorithmic": (91 * 4 + 5 * 4 + 4 + 4 + 5 * 4) * B / (ms * 1e-3) / 1e9}
+        if do_train and buf is not None:
+            Bt = args.train_batch
+            L = DeviceLearner(spec, dev).load_state_dict(sd)
+            tsteps = max(10, min(steps, 30 if "transformer" in combo else 100))
+            u_all = torch.from_numpy(np.random.RandomState(11).random_sample((tsteps + 5, Bt))).to(dev)
+            for i in range(5):
+                L.step(buf, u_all[i], tau=0.005)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(tsteps):
+                L.step(buf, u_all[5 + i], tau=0.005)
+            torch.cuda.synchronize()
+            tw = (time.perf_counter() - t0) / tsteps
+            sf = 4 * (enc_fl + head_fl) * Bt
+            rec["train"] = {"workload": f"PER-DQN step, {combo}, batch {Bt}, {buf.size}-entry replay", "steps": tsteps,
+                            "ms_per_step": tw * 1e3, "value": 1.0 / tw, "unit": "train steps/s",
+                            "dominant_kernel": TRAIN_DOMINANT[combo], "flops_per_step": sf,
+                            "achieved": sf / tw / 1e12, "achieved_unit": "TFLOP/s (algorithmic: 4 x forward FLOPs)",
+                            "frac_executed_pipe": sf / tw / 1e12 / ceil,
+                            "executed_pipe_peak": ceil,
+                            "note": "ceiling = the FORWARD's instruction mix; the backward runs its GRU / head products on "
+                                    "the six-term bf16 split and the weight gradients on fp32 MFMA, so this overstates "
+                                    "the ceiling and understates the fraction",
+                            "loss_last": float(L.loss.item())}
+            del L
+        out.append(rec)
+        del net
+    return out
 
 
 def main():
@@ -162,6 +273,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-trees", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the conv / transformer configurations")
     ap.add_argument("--trees", type=int, default=512, help="MCTS trees per rank (BASELINE config 5)")
     ap.add_argument("--backend", default="nccl", help="collective backend (nccl = RCCL; gloo only to rehearse "
                                                      "several ranks on one GPU)")
@@ -298,7 +410,7 @@ def main():
     wall_d2h = max_over_ranks(time.perf_counter() - t0d)
 
     # --- PER-DQN train steps (config 3), data-parallel over ranks ---------------------------------
-    train = train_weak = None
+    train = train_weak = buf = None
     if not args.no_train:
         from mcts_q_amd.learner import DeviceLearner
         from mcts_q_amd.per import DevicePER
@@ -373,6 +485,13 @@ def main():
         if world > 1:
             train_weak = run_train(args.train_batch * world, "weak (global batch = %d x ranks)" % args.train_batch)
 
+    # --- the other BASELINE configurations (conv / transformer forward, their PER-DQN steps), rank 0 only -----------
+    configs = None
+    if not args.no_configs and rank == 0:
+        configs = other_configs(args, dev, buf if not args.no_train else None, settle, args.steps, args.warmup)
+    if world > 1:
+        dist.barrier()
+
     # --- lock-step MCTS in situ (config 5 shape per rank: `trees` trees x 50 iterations): the C search iteration over
     # the vectorised PtG environment (real step arithmetic on synthetic tables of the real sizes), leaves staged in
     # pinned memory, ONE forward launch per block of trees and iteration, two blocks alternating between host and
@@ -410,7 +529,9 @@ def main():
             "value": world * B * args.steps / wall, "unit": "leaf evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "clock_settle_ms": args.settle_ms,
             "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 via split 16-bit MFMA (fp16 x2 planes / 3 products for the recurrence, bf16 x3 planes / 6 products "
+                     "for the head; fp32 accumulate; ~22-bit products, measured 4e-7..1.1e-6 of max|Q| against fp64)",
             "data": "synthetic U[0,1) windows, seeded default-init weights",
             "config": {"workload": "BASELINE config 2: GRU encoder batched leaf evaluation, "
                                    f"{B} price/process/gas windows per GPU", "encoders": "gru/gru/gru",
@@ -431,6 +552,8 @@ def main():
             res["train_weak"] = train_weak
         if trees is not None:
             res["tree_search"] = trees
+        if configs is not None:
+            res["configs"] = configs
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, ref_net, B, args.train_batch, args.replay)
         print(json.dumps(res), flush=True)
