@@ -359,8 +359,9 @@ int64_t mctsq_per_workspace_bytes(int64_t capacity, int64_t B);
  * workspace (control words + one raw fp64 weight per draw) is a fixed array inside the library's device image:
  * 128.06 KiB per GPU, held until the process ends, so B <= mctsq_per_sample_noalloc_max_draws() (16384) - larger
  * batches are refused with an error.  All calls on one GPU share that array: calls that overlap in time on one
- * GPU (different streams) race; serialise them.  The first call on a device does a one-time set-up (symbol
- * lookup + a 64-byte memset on `stream`); make it outside graph capture. */
+ * GPU (different streams) race; serialise them.  The array that is used is the one of the device `stream` belongs to.
+ * The first call on a device looks the array's address up (a synchronous runtime query, nothing is enqueued for it):
+ * make that call outside stream capture; later calls only launch. */
 int64_t mctsq_per_sample_noalloc_max_draws(void);
 int mctsq_per_sample_noalloc(const uint64_t* d_tree, const double* d_prio, int64_t capacity, int64_t head,
                              int64_t size, const double* d_u, int64_t B, double alpha, double beta,

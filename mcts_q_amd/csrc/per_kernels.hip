@@ -306,15 +306,17 @@ __global__ __launch_bounds__(SMP_THREADS) void per_sample_kernel(PerSampleArgs a
     }
     if (!a.w && !a.wmax) return;
     // ---- the ticket: wave 0 wrote the workgroup's raw weights, so its own wait orders them before its signal ----
+    // (release on the ticket: the wave's raw-weight stores above are ordered before it by the memory model, not only by
+    // the write-through stores having been acknowledged; acquire in the workgroup that finds itself last)
     if (wv == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_last = old == (unsigned)a.nsample - 1 ? 1u : 0u;
         }
     }
     __syncthreads();
     if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double mx = 0.0;
     for (int64_t i = tid; i < a.B; i += SMP_THREADS)
         mx = fmax(mx, __hip_atomic_load(&a.w64[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -548,6 +550,10 @@ __global__ __launch_bounds__(UPD_BULK_THREADS) void per_update_kernel(u64* __res
 // summed in LDS, so each of those nodes receives one global add per launch instead of one per update.  The
 // stamp array is not used on this path.
 constexpr int UPD_FUSED_MAX = 2048, UPD_HASH = 8192;
+// s_key 64 KB + s_mark 32 KB + s_l2 32 KB + s_top: the 160 KB of LDS per workgroup of gfx950 (64 KB on gfx90a / gfx942)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "per_update_fused_kernel's LDS tables are sized for gfx950 (160 KB per workgroup); shrink UPD_HASH for other targets"
+#endif
 __global__ __launch_bounds__(1024) void per_update_fused_kernel(u64* __restrict__ tree, PerTree T,
                                                                 double* __restrict__ prio, int64_t cap,
                                                                 int64_t head, int64_t size,
@@ -924,17 +930,26 @@ namespace {
 std::mutex g_noalloc_mu;
 void* g_noalloc_ptr[64];                 // per device ordinal: address of that device's copy of noalloc_scratch
 
+// The array's address on the device the STREAM belongs to (each GPU holds its own copy at its own address), looked
+// up once per device with that device current.  No memset: a file-scope __device__ array starts zeroed and every
+// sampling launch leaves the control words zero again.  The lookup itself (hipGetSymbolAddress) is a synchronous
+// runtime query, so the FIRST call on a device must be made outside stream capture (include/mctsq_hip.h).
 int noalloc_scratch_ptr(hipStream_t st, void** out) {
     int dev = 0;
-    MCTSQ_HIP(hipGetDevice(&dev));
+    hipDevice_t sdev = 0;
+    if (st != nullptr && hipStreamGetDevice(st, &sdev) == hipSuccess) dev = (int)sdev;
+    else MCTSQ_HIP(hipGetDevice(&dev));
     MCTSQ_CHECK(dev >= 0 && dev < 64, "device ordinal %d out of range", dev);
     std::lock_guard<std::mutex> lk(g_noalloc_mu);
     if (!g_noalloc_ptr[dev]) {
+        int cur = 0;
+        MCTSQ_HIP(hipGetDevice(&cur));
+        if (cur != dev) MCTSQ_HIP(hipSetDevice(dev));
         void* p = nullptr;
-        MCTSQ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(noalloc_scratch)));
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(noalloc_scratch));
+        if (cur != dev) (void)hipSetDevice(cur);
+        MCTSQ_HIP(e);
         MCTSQ_CHECK(p != nullptr, "hipGetSymbolAddress returned NULL for the sampling scratch");
-        // the control words must start at zero; every launch leaves them zero again
-        MCTSQ_HIP(hipMemsetAsync(p, 0, PER_WS_CTRL_BYTES, st));
         g_noalloc_ptr[dev] = p;
     }
     *out = g_noalloc_ptr[dev];

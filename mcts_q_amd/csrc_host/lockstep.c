@@ -144,8 +144,21 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
         }
     }
     if (fail) return -1 - n_new;
+    if (bad) {
+        /* A step failed (clock outside the price tables): take this call's nodes back out of their parents, so the
+           forest is exactly what it was before the call (f->n is not advanced; the rows of the unused ids are scratch) */
+        for (int64_t s = 0; s < n_new; ++s) {
+            const int64_t id = base + s, par = f->parent[id];
+            f->nchild[par] -= 1;
+            f->child[par * N_ACT + f->nchild[par]] = -1;
+            f->tried[par] &= ~((int64_t)1 << f->action[id]);
+        }
+        for (int64_t k = k_lo; k < k_hi; ++k)
+            if (cur[k] >= base) cur[k] = f->parent[cur[k]];
+        return -1 - bad;
+    }
     f->n = base + n_new;
-    return bad ? -1 - bad : n_new;
+    return n_new;
 }
 
 void mctsq_lockstep_backup(mctsq_forest* f, int64_t k_lo, int64_t k_hi, const int64_t* cur, const int64_t* slot_node,
@@ -186,15 +199,25 @@ typedef int (*event_sync_fn)(void*);
 typedef int (*memcpy_fn)(void*, const void*, size_t, int, void*);
 typedef int (*write32_fn)(void*, void*, uint32_t, unsigned);
 
-/* wait until the stream has written `want` to the pinned word (mctsq_leaf_eval.done_flag); gives up after ~20 s */
+/* wait until the stream has written `want` (or a later sequence number: the comparison is wrap-safe) to the pinned word
+ * (mctsq_leaf_eval.done_flag); gives up after MCTSQ_SEARCH_TIMEOUT_S seconds (default 20) */
+static double flag_limit_s(void) {
+    static double limit = -1.0;
+    if (limit < 0.0) {
+        const char* e = getenv("MCTSQ_SEARCH_TIMEOUT_S");
+        const double v = e ? atof(e) : 0.0;
+        limit = v > 0.0 ? v : 20.0;
+    }
+    return limit;
+}
 static int wait_flag(const uint32_t* flag, uint32_t want) {
+    const double LIMIT = flag_limit_s();
     for (int64_t spin = 0;; ++spin) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) return 0;
+        if ((int32_t)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - want) >= 0) return 0;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
         if ((spin & 0xFFFFF) == 0xFFFFF) {
-            static const double LIMIT = 20.0;
             static __thread double t_start = 0.0;
             struct timespec t;
             clock_gettime(CLOCK_MONOTONIC, &t);
@@ -270,8 +293,17 @@ int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, do
         }
     }
     if (rc != 0)                                            /* leave nothing in flight behind an error */
-        for (int64_t h = 0; h < nh; ++h)
-            if (pend[h] > 0) { if (write32) wait_flag(ev->done_flag[h], seq[h]); else ev_sync(ev->event[h]); }
+        for (int64_t h = 0; h < nh; ++h) {
+            if (pend[h] <= 0) continue;
+            /* a real drain where the runtime offers one (an event behind everything queued on the block's stream): a flag
+               that timed out once would only time out again */
+            if (ev_record && ev_sync && ev->event[h] && (!write32 || rc <= -1000)) {
+                if (write32) ev_record(ev->event[h], ev->stream[h]);
+                ev_sync(ev->event[h]);
+            } else if (write32) {
+                wait_flag(ev->done_flag[h], seq[h]);
+            }
+        }
     if (prof) { prof[0] += t_wait; prof[1] += t_backup; prof[2] += t_expand; prof[3] += t_launch; }
     return rc;
 }

@@ -163,6 +163,14 @@ class DeviceLeafEvaluator:
         self._le = le                                                   # keeps the desc byref alive with it
         return le
 
+    def abort(self):
+        """After a failed search: wait for whatever the blocks' streams still hold, then reset the completion words
+        (a late write of an abandoned batch would desynchronise the next search's sequence numbers)."""
+        for st in self._streams:
+            st.synchronize()
+        if hasattr(self, "_flags"):
+            self._flags.zero_()
+
     def stage_ptr(self, h):
         return self._hin[h].data_ptr()
 

@@ -558,6 +558,12 @@ class LockstepMCTS:
             rc = L.mctsq_lockstep_search(fp, env, maxd, cb, ci, self.seed, self.iter_count, self.iterations, sigma,
                                          ctypes.byref(le), curp, slot_all.ctypes.data, tdp, parr)
             if rc < 0:
+                # the iterations that completed stay (their nodes are linked and counted); the failing one was taken
+                # back by the C driver, so the forest is consistent and the next predict() can go on from it
+                self.n = int(f.n)
+                self.iter_count += self.iterations
+                if hasattr(ev, "abort"):
+                    ev.abort()                                   # streams drained, completion words reset
                 raise (IndexError(f"environment step failed for {-1 - rc} states (clock outside the price tables, or "
                                   "staging / node capacity exceeded)") if rc > -1000 else
                        RuntimeError(f"leaf batch launch failed with code {-1000 - rc}"))
@@ -591,6 +597,10 @@ class LockstepMCTS:
                 n_new = L.mctsq_lockstep_expand(fp, env, maxd, cb, ci, self.seed, self.iter_count, lo, hi, sigma, curp,
                                                 slots[h].ctypes.data, ev.stage_ptr(h), ev.cap, tdp)
                 if n_new < 0:
+                    for hh in range(nh):                         # nothing stays in flight; what completed stays in the forest
+                        if pend[hh] is not None:
+                            finish(hh)
+                    self.n = int(f.n)
                     raise IndexError(f"environment step failed for {-1 - n_new} states (clock outside the price tables, "
                                      "or staging / node capacity exceeded)")
                 t1 = clock() if prof is not None else 0.0

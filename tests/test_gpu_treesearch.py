@@ -173,8 +173,8 @@ def test_lockstep_agent_batched_environment():
     assert losses and np.isfinite(losses).all()
 
 
-@pytest.mark.parametrize("zero_copy", [False, True])
-def test_c_driver_with_the_device_evaluator_equals_the_numpy_driver(zero_copy):
+@pytest.mark.parametrize("zero_copy,events", [(False, False), (True, False), (True, True)])
+def test_c_driver_with_the_device_evaluator_equals_the_numpy_driver(zero_copy, events, monkeypatch):
     """SURVEY 8f-2 on the device: the C lock-step driver over the vectorised PtG environment, leaves staged in pinned
     memory and evaluated by one forward launch per block of trees (outputs written to pinned host memory by the kernel),
     the two blocks alternating between host and device - against the numpy driver calling the plain device evaluator
@@ -185,6 +185,11 @@ def test_c_driver_with_the_device_evaluator_equals_the_numpy_driver(zero_copy):
     from mcts_q_amd.ptgenv import PtGBatchEnv
     from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
     from mcts_q_amd.treesearch import LockstepMCTS
+    # completion of a leaf batch: a pinned word the stream writes (default) or an event per batch (MCTSQ_SEARCH_EVENTS)
+    if events:
+        monkeypatch.setenv("MCTSQ_SEARCH_EVENTS", "1")
+    else:
+        monkeypatch.delenv("MCTSQ_SEARCH_EVENTS", raising=False)
     kw = synthetic_ptg_kwargs(5, scale=0.2)
     dqn = DQNModel(1, 6, 2, 5, 64, 2, 128, buffer_capacity=20000, batch_size=64, gamma=0.99, lr=1e-3,
                    price_encoder_type="gru", process_encoder_type="gru", gas_eua_encoder_type="gru", learning_starts=64,

@@ -328,3 +328,108 @@ def test_whole_search_in_one_c_call_equals_the_per_iteration_driver(K, iters, bl
     for x, y in zip(*runs):
         for u, v in zip(x, y):
             assert np.array_equal(u, v)
+
+
+def _late_states(env, K):
+    """States whose clock is a few steps before the end of the price tables: roots observe fine, expansions a few
+    levels down step outside the tables (mctsq_ptg_step_one reports them)."""
+    st = env.reset(np.arange(K))
+    lo, hi = int(st[0, 2]), 10 ** 7
+    while hi - lo > 1:                                            # largest clock the environment still observes
+        mid = (lo + hi) // 2
+        t = st[:1].copy(); t[0, 2] = mid
+        try:
+            env.observe(t); lo = mid
+        except IndexError:
+            hi = mid
+    return st, lo
+
+
+@pytest.mark.parametrize("one_call", [True, False])
+def test_failed_environment_step_leaves_a_searchable_forest(one_call):
+    """A step that fails inside an iteration (clock outside the price tables) raises IndexError and takes the
+    iteration's half-made nodes back: the forest the driver keeps is consistent (every stored node is reachable, counted
+    and linked exactly once) and the same driver searches healthy states afterwards with the result of a fresh one."""
+    from mcts_q_amd.ptgenv import PtGBatchEnv
+    from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
+    K, iters = 140, 12
+    kw = synthetic_ptg_kwargs(6, scale=0.2)
+    env = PtGBatchEnv(kw, seed=1)
+    st, last = _late_states(env, K)
+    good = np.repeat(st[:1], K, axis=0)                           # K trees from one state (their draws differ)
+    bad = good.copy()
+    bad[::7, 2] = last - 1                                        # every seventh tree: one step before the end of the tables
+    ev = _CallbackEvaluator(-(-K // 2), 2) if one_call else _hash_eval
+    drv = LockstepMCTS(K, ev, iters, 6, 19652, 1.25, batch_env=env, seed=5)
+    with pytest.raises(IndexError):
+        drv.predict(bad, train=False)
+    n = drv.n
+    assert 0 < n <= K * (iters + 1)
+    par, nch = drv.parent[:n], drv.nchild[:n]
+    kids = drv.child[:n][drv.child[:n] >= 0]
+    assert len(kids) == len(set(kids.tolist())) == int(nch.sum()) and (kids < n).all()
+    assert np.array_equal(np.sort(kids), np.nonzero(par >= 0)[0])             # linked children == nodes with a parent
+    for c in kids[:200]:
+        p = par[c]
+        assert c in drv.child[p][:nch[p]] and drv.tried[p] >> drv.action[c] & 1
+    assert all(bin(int(drv.tried[i])).count("1") == nch[i] for i in range(n))
+    a = drv.predict(good, train=False)                            # the same driver, healthy states
+    ref = LockstepMCTS(K, _CallbackEvaluator(-(-K // 2), 2) if one_call else _hash_eval, iters, 6, 19652, 1.25,
+                       batch_env=PtGBatchEnv(kw, seed=1), seed=5)
+    ref.iter_count = drv.iter_count - iters                       # same counter-based draws
+    assert np.array_equal(a, ref.predict(good, train=False))
+
+
+def test_completion_words_instead_of_events():
+    """The pinned-word completion path of mctsq_lockstep_search (stream_write32 / done_flag; the default on the GPU)
+    with a host stand-in for hipStreamWriteValue32: same trees as the event path, a NULL done_flag is refused (-3),
+    and sequence numbers that wrap around 2^32 still compare as 'written'."""
+    import ctypes
+    from mcts_q_amd.ptgenv import PtGBatchEnv
+    from mcts_q_amd.synthetic_env import synthetic_ptg_kwargs
+    from mcts_q_amd.treesearch import _tree_lib
+    K, iters = 200, 9
+    kw = synthetic_ptg_kwargs(6, scale=0.2)
+    WR = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint)
+
+    def write32(stream, ptr, value, flags):
+        ctypes.c_uint32.from_address(ptr).value = value
+        return 0
+    runs = []
+    for mode in ("events", "words", "words_wrapping"):
+        ev = _CallbackEvaluator(K // 2, 2)
+        if mode != "events":
+            ev.flags = np.zeros(32, dtype=np.uint32)
+            if mode == "words_wrapping":
+                ev.flags[:] = 2 ** 32 - 3                         # the sequence numbers pass 2^32 during the search
+            ev._wr = WR(write32)
+            ev.le.stream_write32 = ctypes.cast(ev._wr, ctypes.c_void_p).value
+            for h in range(2):
+                ev.le.done_flag[h] = ev.flags.ctypes.data + 64 * h
+        drv = LockstepMCTS(K, ev, iters, 6, 19652, 1.25, batch_env=PtGBatchEnv(kw, seed=1), seed=5)
+        states = drv.batch_env.reset(np.arange(K))
+        a = drv.predict(states, train=False)
+        n = drv.n
+        runs.append([a.copy(), drv.visits[:n].copy(), drv.total[:n].copy(), drv.parent[:n].copy()])
+        if mode == "words":
+            assert int(ev.flags[0]) == iters and int(ev.flags[16]) == iters
+        if mode == "words_wrapping":
+            assert int(ev.flags[0]) == (2 ** 32 - 3 + iters) % 2 ** 32
+    for r in runs[1:]:
+        for u, v in zip(runs[0], r):
+            assert np.array_equal(u, v)
+    # a NULL completion word is refused before anything is launched
+    ev = _CallbackEvaluator(K // 2, 2)
+    ev._wr = WR(write32)
+    ev.le.stream_write32 = ctypes.cast(ev._wr, ctypes.c_void_p).value
+    drv = LockstepMCTS(K, ev, iters, 6, 19652, 1.25, batch_env=PtGBatchEnv(kw, seed=1), seed=5)
+    drv._grow(K * (iters + 2))
+    states = drv.batch_env.reset(np.arange(K))
+    rows, meth = drv.batch_env.observe(states)
+    drv.root[:] = drv._new_nodes_batch(states, rows, meth, -1, -1, False, 0)
+    f = drv._forest_struct()
+    cur, slots = np.empty(K, dtype=np.int64), np.empty(K, dtype=np.int64)
+    rc = _tree_lib().mctsq_lockstep_search(ctypes.byref(f), drv.batch_env.c_env, 6, 19652.0, 1.25, 5, 0, iters, 0.0,
+                                           ctypes.byref(ev.le), cur.ctypes.data, slots.ctypes.data,
+                                           drv.treedepth.ctypes.data, None)
+    assert rc == -3

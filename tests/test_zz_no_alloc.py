@@ -56,6 +56,23 @@ def test_noalloc_sampling_equals_workspace_sampling():
     assert rc == 0 and torch.equal(idx, idx_r) and torch.equal(phys, phys_r) and torch.equal(w, w_r)
 
 
+def test_noalloc_two_streams_in_sequence():
+    """Two calls, one after the other, on two different streams of the device (the scratch is keyed by the stream's
+    device, nothing is enqueued by the set-up): both equal the workspace path."""
+    from mcts_q_amd._lib import lib
+    buf, rng = _ring(n=30000, cap=32768, seed=8)
+    torch.cuda.synchronize()
+    for B, stream in ((700, torch.cuda.Stream()), (64, torch.cuda.Stream())):
+        u = rng.random_sample(B)
+        with torch.cuda.stream(stream):
+            rc, idx, phys, w, _ = _noalloc(buf, u)
+        stream.synchronize()                                  # calls that overlap on one GPU would race (header)
+        assert rc == 0, lib.mctsq_last_error()
+        idx_r, phys_r, w_r = buf.sample_indices(u)
+        torch.cuda.synchronize()
+        assert torch.equal(idx, idx_r) and torch.equal(phys, phys_r) and torch.equal(w, w_r)
+
+
 def test_noalloc_refuses_more_draws_than_its_scratch_holds():
     from mcts_q_amd._lib import lib
     buf, rng = _ring(n=2000, cap=2048)
