@@ -92,6 +92,26 @@ __device__ __forceinline__ void split8h(const float4& x0, const float4& x1, u32x
         hi[p] = __builtin_bit_cast(unsigned, h); lo[p] = __builtin_bit_cast(unsigned, l);
     }
 }
+// ReLU, power-of-two scale and two-way fp16 split of 8 accumulator values in 3 vector instructions per value: the
+// integer maximum (ReLU), one mixed-precision fma that converts s * relu(x) straight into its half of the packed hi
+// word, one that converts s * relu(x) - hi (hi read back as an fp16 source) into its half of the lo word.  Same values
+// as split8h(relu(x) * s): s is a power of two, so every product is exact and each plane is one rounding.  (Left to the
+// compiler, split8h costs 5.5: it converts s * relu(x) twice, once packed for the hi plane and once as the subtrahend.)
+__device__ __forceinline__ void relu_scale_split8h(const f32x4& a, const f32x4& b, const float4& sa, const float4& sb,
+                                                   u32x4& hi, u32x4& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const float s[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r0 = max(__float_as_int(x[2 * p]), 0), r1 = max(__float_as_int(x[2 * p + 1]), 0);
+        unsigned h, l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(s[2 * p]), "v"(r0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(s[2 * p + 1]), "v"(r1));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(s[2 * p]), "v"(r0), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(s[2 * p + 1]), "v"(r1), "v"(h));
+        hi[p] = h; lo[p] = l;
+    }
+}
 // power of two 2^e as a float; e is clamped to the normal range [-126, 127] (exponents outside it only arise from
 // weights or inputs beyond 2^+-100, where the fp32 evaluation overflows as well)
 __device__ __forceinline__ float pow2i(int e) {

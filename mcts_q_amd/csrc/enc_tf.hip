@@ -426,11 +426,7 @@ __device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_SP * FFN_FRAGS * 
         // ---- ReLU, common scale 2^ku, split: the lane's 8 values are k slots 0..7 of the second product ----
         u32x4 uh[NT], ul[NT];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            const float4 v0 = make_float4(relu_bits(ua[tt][0]) * rs0.x, relu_bits(ua[tt][1]) * rs0.y, relu_bits(ua[tt][2]) * rs0.z, relu_bits(ua[tt][3]) * rs0.w);
-            const float4 v1 = make_float4(relu_bits(ub[tt][0]) * rs1.x, relu_bits(ub[tt][1]) * rs1.y, relu_bits(ub[tt][2]) * rs1.z, relu_bits(ub[tt][3]) * rs1.w);
-            split8h(v0, v1, uh[tt], ul[tt]);
-        }
+        for (int tt = 0; tt < NT; ++tt) relu_scale_split8h(ua[tt], ub[tt], rs0, rs1, uh[tt], ul[tt]);
         // ---- out += u . W2^T ----
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
