@@ -244,9 +244,11 @@ int forward_impl(const NetLayout& L, const float* params, const void* prep, cons
         }
         if (nt == 2 ? launch_tf_fwd_pair(t[0], t[1], st) : (nt == 1 ? launch_tf_fwd(t[0], st) : 0)) return -1;
     }
-    if (launch_conv_fwd(ca, save, st)) return -1;          // longest kernels first
+    // longest kernels first; the gas/EUA MLP rides in the conv encoders' launch when there is one
+    const bool mlp_rides = has_mlp && ca.nslots > 0 && B > 0;
+    if (launch_conv_fwd(ca, save, st, mlp_rides ? &ma : nullptr)) return -1;
     if (launch_gru_fwd(ga, save, st)) return -1;
-    if (has_mlp && launch_mlp_fwd(ma, save, st)) return -1;
+    if (has_mlp && !mlp_rides && launch_mlp_fwd(ma, save, st)) return -1;
     if (ev_encoders_done) MCTSQ_HIP(hipEventRecord((hipEvent_t)ev_encoders_done, st));
     return launch_head_fwd(ha, st);
 }

@@ -9,6 +9,7 @@
 // works on a full LDS image with fp32 MFMA.
 // The softmax over time is folded online (one barrier per step), then LayerNorm.
 #include "kernels.hpp"
+#include "mlp_core.hpp"
 #include "learner.hpp"
 #include "pool_core.hpp"
 
@@ -41,12 +42,22 @@ struct ConvFwdLds {
 // 3-6 fp32 MFMAs), splits them into two fp16 planes and writes those into a two-slot LDS buffer, reads the fragments
 // of row t+2 ONCE, and multiplies rows t, t+1, t+2 (taps 0, 1, 2 of conv2) from three rotating register sets.
 // ~20 KB of LDS and ~180 VGPRs let two workgroups (e.g. the price and the process window of one tile) share a CU.
+// Passenger: the first n_mlp workgroups of the grid run the gas/EUA MLP encoder of the same network instead (one 16-sample
+// tile each, mlp_core.hpp: a few microseconds, no dependency either way) - as a launch of its own behind this one it
+// cost its 4.6 us plus a launch boundary of the conv/conv/mlp forward's 40.
 template <bool SAVE>
-__global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args) {
+__global__ __launch_bounds__(256, 2) void conv_enc_fwd_kernel(ConvFwdArgs args, MlpArgs mlp, int n_mlp) {
     __shared__ __attribute__((aligned(16))) ConvFwdLds L;
+    static_assert(sizeof(ConvFwdLds) >= MLP_LDS_FLOATS * sizeof(float), "the passenger's LDS fits the conv encoder's");
+    if ((int)blockIdx.x < n_mlp) {
+        float* lds = reinterpret_cast<float*>(&L);
+        mlp_enc_fwd_body<SAVE>(mlp, lds, lds + TILE * MXLD, (int)blockIdx.x);
+        return;
+    }
     constexpr int XLD = CXLD;
-    const int slot = blockIdx.x % args.nslots;
-    const int64_t row0 = (int64_t)(blockIdx.x / args.nslots) * TILE, Bp = args.Bp;
+    const int cbid = (int)blockIdx.x - n_mlp;
+    const int slot = cbid % args.nslots;
+    const int64_t row0 = (int64_t)(cbid / args.nslots) * TILE, Bp = args.Bp;
     const ConvSlot& s = args.slot[slot];
     const int tid = threadIdx.x, lane = tid & 63, wq = tid >> 6, jl = lane & 15, q = lane >> 4;
     const int j = 16 * wq + jl;
@@ -251,8 +262,8 @@ int launch_conv_prepare(const float* const w2[2], int n, void* prep, hipStream_t
     return 0;
 }
 
-int launch_conv_fwd(const ConvFwdArgs& a, bool save, hipStream_t st) {
-    if (a.nslots == 0 || a.B == 0) return 0;
+int launch_conv_fwd(const ConvFwdArgs& a, bool save, hipStream_t st, const MlpArgs* mlp) {
+    if (a.nslots == 0 || a.B == 0) return mlp ? launch_mlp_fwd(*mlp, save, st) : 0;
     int smax = 0;
     for (int i = 0; i < a.nslots; ++i)
         MCTSQ_CHECK(a.slot[i].wprep && ((uintptr_t)a.slot[i].wprep & 15) == 0, "conv encoder needs prepared weights");
@@ -262,10 +273,17 @@ int launch_conv_fwd(const ConvFwdArgs& a, bool save, hipStream_t st) {
         smax = a.slot[i].S > smax ? a.slot[i].S : smax;
     }
     MCTSQ_CHECK(a.Bp % TILE == 0 && a.Bp >= a.B, "padded batch must be a multiple of %d", TILE);
-    dim3 grid((unsigned)(a.Bp / TILE * a.nslots)), blk(256);
+    MlpArgs m = MlpArgs();
+    int n_mlp = 0;
+    if (mlp) {
+        MCTSQ_CHECK(3 * mlp->F <= 16 && mlp->Bp == a.Bp, "gas/EUA mlp passenger: input width %d > 16 or batch mismatch", 3 * mlp->F);
+        m = *mlp;
+        n_mlp = (int)(a.Bp / TILE);
+    }
+    dim3 grid((unsigned)(a.Bp / TILE * a.nslots + n_mlp)), blk(256);
     (void)smax;
-    if (save) hipLaunchKernelGGL(conv_enc_fwd_kernel<true>, grid, blk, 0, st, a);
-    else hipLaunchKernelGGL(conv_enc_fwd_kernel<false>, grid, blk, 0, st, a);
+    if (save) hipLaunchKernelGGL(conv_enc_fwd_kernel<true>, grid, blk, 0, st, a, m, n_mlp);
+    else hipLaunchKernelGGL(conv_enc_fwd_kernel<false>, grid, blk, 0, st, a, m, n_mlp);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

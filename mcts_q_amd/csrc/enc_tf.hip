@@ -335,16 +335,180 @@ static_assert(FFN_PAIRS % FFN_SP == 0, "staged groups cover the hidden units");
                             // (2) squeezed into 128 registers so that two workgroups share a CU
 #endif
 
+#ifndef MCTSQ_FFN_WAVES
+#define MCTSQ_FFN_WAVES 8   // waves per FFN workgroup (x 16 NT tokens each).  4: two workgroups share a CU, so the two waves of a
+                            // SIMD belong to different barrier domains and drift out of phase
+#endif
+constexpr int FFN_WAVES = MCTSQ_FFN_WAVES, FFN_TOK = FFN_WAVES * 16 * MCTSQ_FFN_NT;
+static_assert(TOK_PER_WG % FFN_TOK == 0, "token padding covers whole FFN workgroups");
+#ifndef MCTSQ_FFN_PIPE
+#define MCTSQ_FFN_PIPE 0    // 1: software-pipelined pair loop (below); 0: the plain loop (one pair start to finish per iteration).
+                            // Measured per 16384-leaf forward: 2.64 ms (1) against 2.14 (0): the compiler keeps V(g) ahead of
+                            // A(g + 1) instead of interleaving them (inline-asm conversions are invisible to its scheduling
+                            // groups) and the accumulator hand-over costs 16 moves per pair; kept for reference
+#endif
+constexpr int FFN_LDS_BUFS = MCTSQ_FFN_PIPE ? 3 : 2;
+
+#if MCTSQ_FFN_PIPE
+// Software-pipelined form.  Per pair of hidden tiles a wave has three jobs in a dependent chain: A = the first product
+// (24 matrix instructions), V = ReLU / rescale / split of its result (vector instructions), B = the second product (24
+// matrix instructions).  Run start to finish per pair, the two waves of a SIMD - released together by the workgroup
+// barrier that ends every pair - do their A at the same time, their V at the same time and wait for their LDS
+// fragments at the same time: the matrix pipe idles through every V and every fragment fetch (MFMA busy 0.54, measured).
+// Here iteration g runs V(g) side by side with A(g + 1), which depends on nothing of pair g, so a wave always has matrix
+// instructions to issue while its vector work and its fragment reads are in flight: V(g) | A(g + 1), then B(g).  The
+// fragments of pairs g and g + 1 are both resident (three LDS buffers; pair g + 2 is staged during the iteration).
 template <int NT>
-__device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_SP * FFN_FRAGS * 64], const TfArgs& a, int layer, int bid) {
+__device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[FFN_LDS_BUFS][FFN_SP * FFN_FRAGS * 64], const TfArgs& a, int layer, int bid) {
+    static_assert(FFN_SP == 1, "the pipelined loop stages one pair per barrier");
+    const TfLayerW& W = a.layer[layer];
+    const TfLayerBuf& Bf = a.buf[layer];
+    const float* hin = Bf.hmid;
+    float* hout = Bf.hout;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
+    constexpr int GFR = FFN_FRAGS * 64;                          // b128 words of one pair's fragments
+    constexpr int NW = FFN_WAVES, NTHR = 64 * NW, NSTG = (GFR + NTHR - 1) / NTHR;
+    const int64_t tok0 = (int64_t)bid * FFN_TOK + w * (16 * NT);
+    const u32x4* prep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]);
+    const TfFfnTables& tb = *reinterpret_cast<const TfFfnTables*>(prep + FFN_TABLES_OFF);
+    u32x4 hh[NT][2], hl[NT][2];
+    {
+        const float sh = pow2i(tb.kh);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + 16 * tt + jl) * E + 32 * c + 8 * q);
+                float4 x0 = p[0], x1 = p[1];
+                x0.x *= sh; x0.y *= sh; x0.z *= sh; x0.w *= sh; x1.x *= sh; x1.y *= sh; x1.z *= sh; x1.w *= sh;
+                split8h(x0, x1, hh[tt][c], hl[tt][c]);
+            }
+    }
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[tt][c] = (f32x4){0, 0, 0, 0};
+    // pairs 0 and 1 -> LDS buffers 0 and 1
+    u32x4 stg[NSTG];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i)
+            if (tid + NTHR * i < GFR) stg[i] = prep[(int64_t)b * GFR + tid + NTHR * i];
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i)
+            if (tid + NTHR * i < GFR) wl[b][tid + NTHR * i] = stg[i];
+    }
+    const float* b1p = tb.b1s + 4 * q;
+    const float* rsp = tb.rs + 4 * q;
+    // first product of one pair: u^T = W1 . h^T on top of the scaled bias (fragments 0..7 of the pair's buffer)
+    auto first_product = [&](const u32x4* wf, const float4& b10, const float4& b11, f32x4 (&ua)[NT], f32x4 (&ub)[NT]) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            ua[tt] = (f32x4){b10.x, b10.y, b10.z, b10.w};
+            ub[tt] = (f32x4){b11.x, b11.y, b11.z, b11.w};
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const u32x4 ah = wf[((0 * 2 + c) * 2 + 0) * 64], al = wf[((0 * 2 + c) * 2 + 1) * 64];
+            const u32x4 bh = wf[((1 * 2 + c) * 2 + 0) * 64], bl = wf[((1 * 2 + c) * 2 + 1) * 64];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                TF_MM3(ua[tt], ah, al, hh[tt][c], hl[tt][c])
+                TF_MM3(ub[tt], bh, bl, hh[tt][c], hl[tt][c])
+            }
+        }
+    };
+    float4 b1n0 = *reinterpret_cast<const float4*>(b1p), b1n1 = *reinterpret_cast<const float4*>(b1p + 16);
+    float4 rsc0 = *reinterpret_cast<const float4*>(rsp), rsc1 = *reinterpret_cast<const float4*>(rsp + 16);
+    __syncthreads();
+    f32x4 ua[NT], ub[NT];
+    first_product(&wl[0][lane], b1n0, b1n1, ua, ub);             // A(0)
+    b1n0 = *reinterpret_cast<const float4*>(b1p + 32); b1n1 = *reinterpret_cast<const float4*>(b1p + 32 + 16);
+    int cur = 0;                                                 // LDS buffer of pair g (g % 3 without the division)
+#pragma unroll 1
+    for (int g = 0; g < FFN_PAIRS; ++g) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nn = nxt == 2 ? 0 : nxt + 1;
+        const float4 rs0 = rsc0, rs1 = rsc1, b10 = b1n0, b11 = b1n1;
+        if (g + 2 < FFN_PAIRS) {                                 // fragments of pair g + 2 start their trip
+#pragma unroll
+            for (int i = 0; i < NSTG; ++i)
+                if (tid + NTHR * i < GFR) stg[i] = prep[(int64_t)(g + 2) * GFR + tid + NTHR * i];
+        }
+        if (g + 1 < FFN_PAIRS) {                                 // scales of pair g + 1, bias of pair g + 2
+            rsc0 = *reinterpret_cast<const float4*>(rsp + (g + 1) * 32); rsc1 = *reinterpret_cast<const float4*>(rsp + (g + 1) * 32 + 16);
+        }
+        if (g + 2 < FFN_PAIRS) {
+            b1n0 = *reinterpret_cast<const float4*>(b1p + (g + 2) * 32); b1n1 = *reinterpret_cast<const float4*>(b1p + (g + 2) * 32 + 16);
+        }
+        // W2 fragments of pair g: requested first, used last
+        const u32x4* wf = &wl[cur][lane];
+        u32x4 yh[4], yl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { yh[c] = wf[(8 + c * 2 + 0) * 64]; yl[c] = wf[(8 + c * 2 + 1) * 64]; }
+        // V(g): ReLU, common scale 2^ku, split -- vector work, in the shadow of A(g + 1)'s matrix instructions
+        u32x4 uh[NT], ul[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) relu_scale_split8h(ua[tt], ub[tt], rs0, rs1, uh[tt], ul[tt]);
+        // A(g + 1)
+        f32x4 va[NT], vb[NT];
+        if (g + 1 < FFN_PAIRS) first_product(&wl[nxt][lane], b10, b11, va, vb);
+        // B(g): out += u . W2^T
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) { TF_MM3(acc[tt][c], uh[tt], ul[tt], yh[c], yl[c]) }
+        if (g + 2 < FFN_PAIRS) {
+#pragma unroll
+            for (int i = 0; i < NSTG; ++i)
+                if (tid + NTHR * i < GFR) wl[nn][tid + NTHR * i] = stg[i];
+        }
+        __syncthreads();
+        if (g + 1 < FFN_PAIRS) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) { ua[tt] = va[tt]; ub[tt] = vb[tt]; }
+        }
+        cur = nxt;
+    }
+    if (tok0 >= a.T) return;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        float x[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float bias = W.l2b[16 * c + jl], inv = tb.inv2[16 * c + jl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[c][r] = (acc[tt][c][r] * inv + bias) + hin[(tok0 + 16 * tt + 4 * q + r) * E + 16 * c + jl];
+        }
+        {
+            const int64_t t0 = tok0 + 16 * tt;
+            const int64_t left = a.T - t0;
+            ln_rows(x, W.n2w, W.n2b, jl, q, Bf.x2 ? Bf.x2 + t0 * E : nullptr, Bf.x2 ? Bf.st2 + t0 * 2 : nullptr,
+                    (int)(left < 16 ? (left < 0 ? 0 : left) : 16));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t tok = tok0 + 16 * tt + 4 * q + r;
+            if (tok < a.T) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hout[tok * E + 16 * c + jl] = x[c][r];
+            }
+        }
+    }
+}
+#else
+template <int NT>
+__device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[FFN_LDS_BUFS][FFN_SP * FFN_FRAGS * 64], const TfArgs& a, int layer, int bid) {
     const TfLayerW& W = a.layer[layer];
     const TfLayerBuf& Bf = a.buf[layer];
     const float* hin = Bf.hmid;
     float* hout = Bf.hout;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
     constexpr int SP = FFN_SP, GFR = SP * FFN_FRAGS * 64;       // pairs per staged group (one barrier per group), its b128 count
-    constexpr int NW = 16 / NT, NTHR = 64 * NW, NSTG = (GFR + NTHR - 1) / NTHR;   // waves, threads, staged b128 per thread
-    const int64_t tok0 = (int64_t)bid * TOK_PER_WG + w * (16 * NT);            // < Tp (Tp / 256 blocks per encoder)
+    constexpr int NW = FFN_WAVES, NTHR = 64 * NW, NSTG = (GFR + NTHR - 1) / NTHR;   // waves, threads, staged b128 per thread
+    const int64_t tok0 = (int64_t)bid * FFN_TOK + w * (16 * NT);               // < Tp
     const u32x4* prep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]);
     const TfFfnTables& tb = *reinterpret_cast<const TfFfnTables*>(prep + FFN_TABLES_OFF);
     // B operand of the first product: 2^kh h^T, lane (token jl, k group q) holds h[token][32c + 8q .. +7], split
@@ -471,17 +635,19 @@ __device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[2][FFN_SP * FFN_FRAGS * 
     }
 }
 
+#endif
+
 template <int NT>
-__global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_kernel(TfArgs a, int layer) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_SP * FFN_FRAGS * 64];   // 32 KB per staged pair
+__global__ __launch_bounds__(64 * FFN_WAVES, 2) void tf_ffn_kernel(TfArgs a, int layer) {
+    __shared__ __attribute__((aligned(16))) u32x4 wl[FFN_LDS_BUFS][FFN_SP * FFN_FRAGS * 64];   // 16 KB per staged pair
     tf_ffn_body<NT>(wl, a, layer, (int)blockIdx.x);
 }
 // The FFN blocks of TWO encoders (price and process window of one network) as one grid: launched one after the
 // other, each grid ends with a round in which most CUs idle (1600 and 640 workgroups on 256 CUs: 7 + 3 rounds);
 // together they take 9.
 template <int NT>
-__global__ __launch_bounds__(64 * (16 / NT)) void tf_ffn_pair_kernel(TfArgs a, TfArgs b, int na, int layer) {
-    __shared__ __attribute__((aligned(16))) u32x4 wl[2][FFN_SP * FFN_FRAGS * 64];
+__global__ __launch_bounds__(64 * FFN_WAVES, 2) void tf_ffn_pair_kernel(TfArgs a, TfArgs b, int na, int layer) {
+    __shared__ __attribute__((aligned(16))) u32x4 wl[FFN_LDS_BUFS][FFN_SP * FFN_FRAGS * 64];
     if ((int)blockIdx.x < na) tf_ffn_body<NT>(wl, a, layer, (int)blockIdx.x);
     else tf_ffn_body<NT>(wl, b, layer, (int)blockIdx.x - na);
 }
@@ -633,10 +799,10 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
     MCTSQ_CHECK(a.NS >= 1 && a.NS * a.S <= AROWS, "transformer encoder: samples per workgroup");
     MCTSQ_CHECK(a.ffn_prep[0] && a.ffn_prep[1], "transformer encoder needs prepared FFN weights");
     hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp / 16)), dim3(256), 0, st, a);
-    const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / TOK_PER_WG);
+    const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / FFN_TOK);
     for (int l = 0; l < 2; ++l) {
         hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(256), 0, st, a, l);
-        hipLaunchKernelGGL(tf_ffn_kernel<MCTSQ_FFN_NT>, dim3(ffn_grid), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st, a, l);
+        hipLaunchKernelGGL(tf_ffn_kernel<MCTSQ_FFN_NT>, dim3(ffn_grid), dim3(64 * FFN_WAVES), 0, st, a, l);
     }
     hipLaunchKernelGGL(tf_pool_kernel, dim3((unsigned)((a.Bp + 3) / 4)), dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
@@ -657,11 +823,11 @@ int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st) {
     if (tf_check(a) || tf_check(b)) return -1;
     MCTSQ_CHECK(a.B == b.B, "transformer encoder pair: batch mismatch");
     hipLaunchKernelGGL(tf_embed_pair_kernel, dim3((unsigned)(a.Tp / 16 + b.Tp / 16)), dim3(256), 0, st, a, b, (int)(a.Tp / 16));
-    const int na = (int)(a.Tp / TOK_PER_WG), nb = (int)(b.Tp / TOK_PER_WG);
+    const int na = (int)(a.Tp / FFN_TOK), nb = (int)(b.Tp / FFN_TOK);
     for (int l = 0; l < 2; ++l) {
         const int ga = (int)((a.B + a.NS - 1) / a.NS), gb = (int)((b.B + b.NS - 1) / b.NS);
         hipLaunchKernelGGL(tf_attn_pair_kernel, dim3((unsigned)(ga + gb)), dim3(256), 0, st, a, b, ga, l);
-        hipLaunchKernelGGL(tf_ffn_pair_kernel<MCTSQ_FFN_NT>, dim3((unsigned)(na + nb)), dim3(64 * (16 / MCTSQ_FFN_NT)), 0, st,
+        hipLaunchKernelGGL(tf_ffn_pair_kernel<MCTSQ_FFN_NT>, dim3((unsigned)(na + nb)), dim3(64 * FFN_WAVES), 0, st,
                            a, b, na, l);
     }
     hipLaunchKernelGGL(tf_pool_pair_kernel, dim3((unsigned)((a.Bp + 3) / 4 + (b.Bp + 3) / 4)), dim3(256), 0, st, a, b,

@@ -72,7 +72,9 @@ struct ConvFwdArgs {
     int64_t B, Bp;
     float* feats;                        // [Bp][192]
 };
-int launch_conv_fwd(const ConvFwdArgs& args, bool save, hipStream_t st);
+struct MlpArgs;
+// mlp != NULL: the gas/EUA MLP encoder of the same network rides in the same launch (enc_conv.hip)
+int launch_conv_fwd(const ConvFwdArgs& args, bool save, hipStream_t st, const MlpArgs* mlp = nullptr);
 // conv2 weight [64 out][64 in][3 taps] fp32 -> split-fp16 fragments in the order the forward kernel loads them:
 // u32x4 [wave 4][K chunk 6 = 2 tap + half][plane 2][lane 64]; lane (jl, q) holds W2[16 wave + jl][32 half + 8q .. +7][tap]
 // times the output channel's power of two; the 64 channel exponents follow
