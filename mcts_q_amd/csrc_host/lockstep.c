@@ -68,9 +68,29 @@ static inline int64_t select_leaf(const mctsq_forest* f, int64_t cur, int64_t ma
     }
 }
 
-int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, double c_base, double c_init,
-                              uint64_t seed, uint64_t iteration, int64_t k_lo, int64_t k_hi, double noise_sigma,
-                              int64_t* cur, int64_t* slot_node, float* stage, int64_t stage_cap, int64_t* treedepth) {
+/* value assignment + backup of ONE tree (the body of mctsq_lockstep_backup) */
+static inline void backup_tree(mctsq_forest* f, int64_t node, int64_t first, const float* vmax_out, const float* prior_out,
+                               int64_t n_act) {
+    if (node >= first) {                                            /* this iteration's new leaf: ids are consecutive */
+        const int64_t s = node - first;
+        f->vmax[node] = (double)vmax_out[s];                        /* q.max().item() (:370) */
+        f->prior_a[node] = (double)prior_out[s * n_act + f->action[node]];   /* prior[idx, action].item() (:296) */
+    }
+    const double value = f->vmax[node];
+    while (node >= 0) {
+        f->visits[node] += 1;
+        f->total[node] += value;
+        node = f->parent[node];
+    }
+}
+
+/* bk_* (optional): the backup of the block's PREVIOUS iteration, done by every thread for its own trees at the start
+   of the same parallel region (the partition of the trees over the threads is the same in both phases, so a tree's
+   backup and its next selection need no barrier between them): one fork / join per block and iteration instead of two */
+static int64_t expand_impl(mctsq_forest* f, const void* env, int64_t maxd, double c_base, double c_init,
+                           uint64_t seed, uint64_t iteration, int64_t k_lo, int64_t k_hi, double noise_sigma,
+                           int64_t* cur, int64_t* slot_node, float* stage, int64_t stage_cap, int64_t* treedepth,
+                           int64_t bk_n_new, const float* bk_vmax, const float* bk_prior, int64_t bk_n_act) {
     const int64_t nk = k_hi - k_lo, D = f->D, W = f->row_w, P = W - 6 - (D - MCTSQ_PTG_STATE_HEAD);
     const int64_t L6 = D - MCTSQ_PTG_STATE_HEAD;
     if (nk <= 0) return 0;
@@ -80,6 +100,7 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
        them node ids - are in tree order whatever the thread count */
     int64_t n_new = 0, bad = 0, fail = 0;
     const int64_t base = f->n;
+    const int64_t bk_first = bk_n_new > 0 ? slot_node[0] : INT64_MAX;      /* read before this call reuses the slots */
     int64_t counts[64];
     int T = tree_threads();
     if (T > 64) T = 64;
@@ -89,6 +110,8 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
         const int nt = omp_get_num_threads(), tid = omp_get_thread_num();
         const int64_t lo = k_lo + nk * tid / nt, hi = k_lo + nk * (tid + 1) / nt;
         int64_t c = 0;
+        if (bk_n_new >= 0)
+            for (int64_t k = lo; k < hi; ++k) backup_tree(f, cur[k], bk_first, bk_vmax, bk_prior, bk_n_act);
         for (int64_t k = lo; k < hi; ++k) {
             const int64_t leaf = select_leaf(f, f->root[k], maxd, c_base, c_init);
             cur[k] = leaf;
@@ -161,6 +184,13 @@ int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, do
     return n_new;
 }
 
+int64_t mctsq_lockstep_expand(mctsq_forest* f, const void* env, int64_t maxd, double c_base, double c_init,
+                              uint64_t seed, uint64_t iteration, int64_t k_lo, int64_t k_hi, double noise_sigma,
+                              int64_t* cur, int64_t* slot_node, float* stage, int64_t stage_cap, int64_t* treedepth) {
+    return expand_impl(f, env, maxd, c_base, c_init, seed, iteration, k_lo, k_hi, noise_sigma, cur, slot_node, stage,
+                       stage_cap, treedepth, -1, NULL, NULL, 0);
+}
+
 void mctsq_lockstep_backup(mctsq_forest* f, int64_t k_lo, int64_t k_hi, const int64_t* cur, const int64_t* slot_node,
                            int64_t n_new, const float* vmax_out, const float* prior_out, int64_t n_act) {
     /* Same partition of the trees over the threads as in expand: a tree's nodes are then read and written by one
@@ -174,20 +204,7 @@ void mctsq_lockstep_backup(mctsq_forest* f, int64_t k_lo, int64_t k_hi, const in
     {
         const int nt = omp_get_num_threads(), tid = omp_get_thread_num();
         const int64_t lo = k_lo + nk * tid / nt, hi = k_lo + nk * (tid + 1) / nt;
-        for (int64_t k = lo; k < hi; ++k) {
-            int64_t node = cur[k];
-            if (node >= first) {                                            /* this iteration's new leaf: ids are consecutive */
-                const int64_t s = node - first;
-                f->vmax[node] = (double)vmax_out[s];                        /* q.max().item() (:370) */
-                f->prior_a[node] = (double)prior_out[s * n_act + f->action[node]];   /* prior[idx, action].item() (:296) */
-            }
-            const double value = f->vmax[node];
-            while (node >= 0) {
-                f->visits[node] += 1;
-                f->total[node] += value;
-                node = f->parent[node];
-            }
-        }
+        for (int64_t k = lo; k < hi; ++k) backup_tree(f, cur[k], first, vmax_out, prior_out, n_act);
     }
 }
 
@@ -265,14 +282,19 @@ int64_t mctsq_lockstep_search(mctsq_forest* f, const void* env, int64_t maxd, do
                     if (e) { rc = -1000 - e; break; }
                 }
                 double t1 = prof ? now_s() : 0.0;
-                mctsq_lockstep_backup(f, lo, hi, cur, slots + lo, pend[h], ev->vmax[h], ev->prior[h], ev->n_act);
-                pend[h] = -1;
+                if (it == iterations) {                              /* the draining round: nothing follows the backup */
+                    mctsq_lockstep_backup(f, lo, hi, cur, slots + lo, pend[h], ev->vmax[h], ev->prior[h], ev->n_act);
+                    pend[h] = -1;
+                }
                 if (prof) { t_wait += t1 - t0; t_backup += now_s() - t1; }
             }
             if (it == iterations) continue;
             double t0 = prof ? now_s() : 0.0;
-            const int64_t n_new = mctsq_lockstep_expand(f, env, maxd, c_base, c_init, seed, iteration0 + (uint64_t)it, lo,
-                                                        hi, noise_sigma, cur, slots + lo, ev->stage[h], cap, treedepth);
+            /* the block's pending backup rides at the head of this expand's parallel region */
+            const int64_t n_new = expand_impl(f, env, maxd, c_base, c_init, seed, iteration0 + (uint64_t)it, lo, hi,
+                                              noise_sigma, cur, slots + lo, ev->stage[h], cap, treedepth, pend[h],
+                                              ev->vmax[h], ev->prior[h], ev->n_act);
+            pend[h] = -1;
             if (n_new < 0) { rc = n_new; break; }
             double t1 = prof ? now_s() : 0.0;
             if (n_new > 0) {
