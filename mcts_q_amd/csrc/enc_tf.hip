@@ -331,13 +331,21 @@ __global__ __launch_bounds__(256, 3) void tf_attn_pair_kernel(TfArgs a, TfArgs b
 constexpr int FFN_SP = MCTSQ_FFN_SP;
 static_assert(FFN_PAIRS % FFN_SP == 0, "staged groups cover the hidden units");
 #ifndef MCTSQ_FFN_NT
-#define MCTSQ_FFN_NT 2      // token tiles of 16 per wave; measured per 16384-leaf forward: 2.55 ms (1), 2.41 (2), 2.98 (4); 3.07 for
-                            // (2) squeezed into 128 registers so that two workgroups share a CU
+#define MCTSQ_FFN_NT 4      // token tiles of 16 per wave; measured per 16384-leaf forward with 8 waves of NT tiles per CU-filling
+                            // workgroup: 2.55 ms (1), 2.41 (2), 2.98 (4: one wave per SIMD); 3.07 for (2) squeezed into 128
+                            // registers so that two workgroups share a CU.  With FOUR waves per workgroup and two workgroups
+                            // per CU (MCTSQ_FFN_WAVES below; 242 registers, two waves per SIMD): 2.12 (2) -> 1.98 (4): every
+                            // fragment a wave reads from LDS serves four token tiles, and the fragment reads - which the
+                            // barrier per pair keeps from overlapping the matrix instructions - drop from 0.75 to 0.42 of
+                            // the matrix time
 #endif
 
+#ifndef MCTSQ_FFN_TTMAJOR
+#define MCTSQ_FFN_TTMAJOR 1  // pair loop body token tile by token tile (see there); 0: unit tile by unit tile
+#endif
 #ifndef MCTSQ_FFN_WAVES
-#define MCTSQ_FFN_WAVES 8   // waves per FFN workgroup (x 16 NT tokens each).  4: two workgroups share a CU, so the two waves of a
-                            // SIMD belong to different barrier domains and drift out of phase
+#define MCTSQ_FFN_WAVES 4   // waves per FFN workgroup (x 16 NT tokens each).  4: two workgroups share a CU (the two waves of a
+                            // SIMD belong to different barrier domains); 8 at NT = 2 measured 2.12 ms against 2.09 for 4
 #endif
 constexpr int FFN_WAVES = MCTSQ_FFN_WAVES, FFN_TOK = FFN_WAVES * 16 * MCTSQ_FFN_NT;
 static_assert(TOK_PER_WG % FFN_TOK == 0, "token padding covers whole FFN workgroups");
@@ -570,6 +578,34 @@ __device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[FFN_LDS_BUFS][FFN_SP * F
         const float4 b10 = b1c[sp][0], b11 = b1c[sp][1], rs0 = rsc[sp][0], rs1 = rsc[sp][1];
         const u32x4* wf = &wl[buf][sp * (FFN_FRAGS * 64) + lane];
         // every weight fragment is read from LDS once per wave and pair and serves all NT token tiles
+#if MCTSQ_FFN_TTMAJOR
+        // Token tile by token tile: tile tt's first product, then its ReLU / split - vector work that depends only on
+        // tile tt's accumulators, so it can issue in the shadow of tile tt + 1's matrix instructions - and the second
+        // product's fragments are requested before the first product starts.  (Unit tile by unit tile over all token
+        // tiles, all of a pair's vector work sat in one burst between the two products with the matrix pipe idle.)
+        u32x4 w1h[2][2], w1l[2][2], yh[4], yl[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { w1h[m][c] = wf[((m * 2 + c) * 2 + 0) * 64]; w1l[m][c] = wf[((m * 2 + c) * 2 + 1) * 64]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { yh[c] = wf[(8 + c * 2 + 0) * 64]; yl[c] = wf[(8 + c * 2 + 1) * 64]; }
+        u32x4 uh[NT], ul[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            f32x4 ua = {b10.x, b10.y, b10.z, b10.w}, ub = {b11.x, b11.y, b11.z, b11.w};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                TF_MM3(ua, w1h[0][c], w1l[0][c], hh[tt][c], hl[tt][c])
+                TF_MM3(ub, w1h[1][c], w1l[1][c], hh[tt][c], hl[tt][c])
+            }
+            relu_scale_split8h(ua, ub, rs0, rs1, uh[tt], ul[tt]);
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { TF_MM3(acc[tt][c], uh[tt], ul[tt], yh[c], yl[c]) }
+#else
         // ---- u^T = W1 . h^T for the pair's two unit tiles, on top of the (scaled) bias of hidden unit 4q + r ----
         f32x4 ua[NT], ub[NT];
 #pragma unroll
@@ -598,6 +634,7 @@ __device__ __forceinline__ void tf_ffn_body(u32x4 (&wl)[FFN_LDS_BUFS][FFN_SP * F
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) { TF_MM3(acc[tt][c], uh[tt], ul[tt], yh, yl) }
         }
+#endif
       }
         if (g + 1 < FFN_PAIRS / SP) {
 #pragma unroll
