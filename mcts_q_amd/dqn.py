@@ -17,7 +17,6 @@ There is no CPU fallback: constructing these classes without a GPU raises MctsqE
 from __future__ import annotations
 
 import random
-from collections import deque
 
 import numpy as np
 import torch
@@ -239,20 +238,19 @@ class PrioritizedReplayBuffer:
         self.dev.update_priorities(indices, priorities)
 
     # ---- checkpoint interchange (:487-492, :504-508) ------------------------------------------
+    # The reference's attributes are deques (save / load touch `.buffer.maxlen`, `list(.buffer)`, `list(.priorities)`).
+    # Here they are read-only VIEWS of the device ring in logical order: len() and maxlen cost nothing, indexing
+    # copies the one record, iteration streams the ring in chunks - nothing rebuilds a million-entry deque of
+    # observation dicts because a caller asked for `len(rb.buffer)`.
     @property
     def priorities(self):
         self.flush()
-        return deque(self.dev.logical_priorities().tolist(), maxlen=self.capacity)
+        return _RingView(self, "priorities")
 
     @property
     def buffer(self):
         self.flush()
-        d = self.dev
-        order = (d.head + np.arange(d.size)) % d.capacity
-        s, n = d.states.cpu().numpy()[order], d.next_states.cpu().numpy()[order]
-        a, r, dn = d.actions.cpu().numpy()[order], d.rewards.cpu().numpy()[order], d.dones.cpu().numpy()[order]
-        return deque(((row_to_obs(s[i]), int(a[i]), float(r[i]), row_to_obs(n[i]), bool(dn[i]))
-                      for i in range(d.size)), maxlen=self.capacity)
+        return _RingView(self, "transitions")
 
     def load_lists(self, buffer, priorities) -> None:
         """Rebuild the device ring from the reference's list form."""
@@ -268,6 +266,52 @@ class PrioritizedReplayBuffer:
                            np.stack([obs_to_row(t[3]) for t in items]),
                            np.asarray([float(t[4]) for t in items], dtype=np.float32))
         self.dev.set_priorities_exact(prio)
+
+
+class _RingView:
+    """Sequence view of the device ring in logical order (index 0 = oldest entry), standing in for the reference's
+    `deque(maxlen=capacity)` attributes: `len`, `maxlen`, indexing (negative too), iteration, `list(...)`."""
+    CHUNK = 65536
+
+    def __init__(self, rb: "PrioritizedReplayBuffer", what: str):
+        self._rb, self._what, self.maxlen = rb, what, rb.capacity
+
+    def __len__(self):
+        return self._rb.dev.size
+
+    def _fetch(self, lo: int, hi: int):
+        d = self._rb.dev
+        phys = torch.as_tensor((d.head + np.arange(lo, hi)) % d.capacity, device=d.device)
+        if self._what == "priorities":
+            return d.prio[phys].cpu().numpy().tolist()
+        s, n = d.states[phys].cpu().numpy(), d.next_states[phys].cpu().numpy()
+        a, r, dn = d.actions[phys].cpu().numpy(), d.rewards[phys].cpu().numpy(), d.dones[phys].cpu().numpy()
+        return [(row_to_obs(s[i]), int(a[i]), float(r[i]), row_to_obs(n[i]), bool(dn[i])) for i in range(hi - lo)]
+
+    def __getitem__(self, i):
+        n = len(self)
+        if isinstance(i, slice):
+            raise TypeError("sequence index must be integer, not 'slice'")          # as collections.deque
+        i = int(i)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("deque index out of range")
+        return self._fetch(i, i + 1)[0]
+
+    def __iter__(self):
+        n = len(self)
+        for lo in range(0, n, self.CHUNK):
+            yield from self._fetch(lo, min(lo + self.CHUNK, n))
+
+    def __array__(self, dtype=None, copy=None):                 # np.array(rb.priorities): one pass, not one fetch per index
+        if self._what == "priorities":
+            out = np.asarray(self._rb.dev.logical_priorities())
+            return out.astype(dtype) if dtype is not None else out
+        out = np.empty(len(self), dtype=object)
+        for i, t in enumerate(self):
+            out[i] = t
+        return out
 
 
 class _AdamFacade:

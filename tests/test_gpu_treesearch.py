@@ -61,6 +61,21 @@ def test_lockstep_hip_search_matches_reference_search():
             bad += 1
     print(f"identical root visit distributions: {same}/{K}")
     assert same >= int(0.9 * K) and bad == 0
+    # With the SAME network on both sides - the per-node search calling the HIP forward one state at a time, as the
+    # reference calls its module (mcts_per.py:291-296, 367-370) - nothing is left to rounding: the forward is row-wise,
+    # so batch composition cannot change a value, and every tree must come out identical, node for node.
+    def q_hip(p, q, g):
+        return net(p.cuda(), q.cuda(), g.cuda())["q"].cpu()
+    for i in range(K):
+        ref = mcts_ref.RefSearch(q_hip, envs[i], iters, 42, 19652, 1.25, random.Random(7 + i))
+        assert ref.predict(scs[i], "eval") == acts[i]
+        stack = [(ref.root, int(drv.root[i]))]
+        while stack:
+            rn, dn = stack.pop()
+            assert (rn.visits, rn.total_value) == (int(drv.visits[dn]), float(drv.total[dn]))
+            kids = [int(c) for c in drv.child[dn][:drv.nchild[dn]]]
+            assert [c.action for c in rn.children] == [int(drv.action[c]) for c in kids]
+            stack.extend(zip(rn.children, kids))
 
 
 def test_mctsq_learn_predict_save_load(tmp_path):
