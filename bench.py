@@ -115,7 +115,7 @@ def profile_numbers():
     (tools/profile_bench.sh), newest round first: HBM bytes per launch of the dominant kernel from the PMC passes
     (FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) and the share of SIMD time its matrix pipe is busy."""
     out = {"traffic": None, "traffic_source": None, "mfma_busy": None, "mfma_busy_source": None}
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if out["traffic"] is None and os.path.exists(path):
             with open(path) as f:
@@ -477,8 +477,8 @@ def main():
                                  "activation_record_bytes": act_bytes, "algorithmic_bytes_per_step": step_bytes,
                                  "hbm_GBs_algorithmic": step_bytes / (twall / tsteps) / 1e9,
                                  "hbm_frac": step_bytes / (twall / tsteps) / 1e9 / HBM_PEAK_GBS,
-                                 "per_kernel": "profiles/r02_train_step_gru_B1024_kernel_stats.csv (rocprofv3 of "
-                                               "tools/train_loop.py) and profiles/r02_pmc_traffic.json"}}
+                                 "per_kernel": "profiles/r03_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this "
+                                               "program), profiles/r03_pmc_traffic.json, profiles/r03_sq_counters.json"}}
 
         train = run_train(args.train_batch, "strong (global batch fixed; replay shards sampled as one buffer, each rank "
                           "back-propagates its own draws; one flat-gradient all-reduce)" if world > 1 else "single GPU")
