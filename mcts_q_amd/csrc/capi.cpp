@@ -23,7 +23,7 @@ static void fill_gru_slot(GruSlot& g, const EncOff& e, const float* params, cons
     if (sv) {
         g.sv_h = sv->h; g.sv_r = sv->r; g.sv_z = sv->z; g.sv_n = sv->n; g.sv_hn = sv->hn;
         g.sv_score = sv->score; g.sv_stat = sv->stat; g.sv_pool = sv->pool; g.sv_x = sv->x;
-        g.bw_g = sv->g; g.bw_dsc = sv->dsc; g.bw_p = sv->p; g.bw_aw = sv->aw; g.bw_ln = sv->ln;
+        g.bw_wih = sv->wih; g.bw_wrz = sv->wrz; g.bw_wn = sv->wn; g.bw_dsc = sv->dsc; g.bw_p = sv->p; g.bw_aw = sv->aw; g.bw_ln = sv->ln;
     }
 }
 

@@ -10,7 +10,7 @@ struct SlotSave {
     // shared by the attention-pooled encoders (GRU, conv)
     float *score, *stat, *pool, *x, *dsc, *p;
     // GRU-attention (kernels.hpp: GruSlot)
-    float *h, *r, *z, *n, *hn, *g, *aw, *ln;
+    float *h, *r, *z, *n, *hn, *wih, *wrz, *wn, *aw, *ln;
     // Conv-attention (kernels.hpp: ConvSlot)
     float *c_h1, *c_h2, *c_d2, *c_d1;
     // gas/EUA MLP (kernels.hpp: MlpArgs)

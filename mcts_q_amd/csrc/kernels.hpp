@@ -22,7 +22,9 @@ struct GruSlot {
     float* sv_pool;                      // [Bp][64] pooled vector before LayerNorm
     float* sv_x;                         // [S][Bp][8] time-major window incl. time features, zero padded
     // backward outputs (learner.hip)
-    float* bw_g;                         // [S][tile][4 = d(pre-activation) r | z | n | n*r] lane-major blocks of 1024
+    // per-workgroup partials of the weight gradients, accumulated inside the backward kernel, in the layout of three
+    // reduction jobs: W_ih + b_ih [192*F + 192], W_hh / b_hh rows r, z [128*64 + 128], rows n [64*64 + 64]
+    float *bw_wih, *bw_wrz, *bw_wn;
     float* bw_dsc;                       // [S][Bp] d(score)
     float* bw_p;                         // [Bp][64] dfeat * xhat (LayerNorm weight gradient terms)
     float* bw_aw;                        // [workgroups][65] per-workgroup partials of the score Linear(64,1) gradient

@@ -329,7 +329,31 @@ struct GruBwdLds {
     unsigned short gp[2][3][TILE * GPL];   // delta tile [drp | dzp | ghn] as bf16 planes (hi, mid, lo), double buffered
     float4 pe[MAX_SEQ][TILE];       // per-wave partials of e_t = dpool . h_t
     float red[3][4][TILE];
+    u32x4 hx[2][4 * 3 * 64];        // weight gradients: every wave's h_{t-1} operand [wave][plane][lane], two buffers
 };
+
+// ---- weight gradients inside the BPTT kernel -------------------------------------------------------------------
+// dW_hh = G^T H_prev and dW_ih = G^T X contract over (step, sample), and the registers a lane holds anyway ARE matrix
+// operands of those products: lane (jl, q) of wave w has, per step, the deltas and h_{t-1} of unit 16w + jl for its
+// RPL samples - as the A operand row jl (a gate row of this wave's units) resp. the B operand column jl (a hidden
+// column), K block q.  Any assignment of (step, sample) pairs to the K slots of a block is fine as long as both
+// operands use the same one, so the operands are filled in place, step by step:
+//   RPL 2 (8-sample workgroups): K = 32 = 3 steps x 2 samples per lane block (+ 2 zero slots), one group of
+//         products ("flush") every third step - the step loop runs in triples already;
+//   RPL 4 (16-sample workgroups): K = 16 = 1 step x 4 samples, the 16x16x16 instruction, a flush every step.
+// Both operands go through the exact three-way bf16 split (six cross terms), as the BPTT product does: the deltas
+// have no bound.  A wave owns the gate rows of its 16 units against ALL 64 hidden columns, so the four waves swap
+// their H operands through LDS (12 KB per flush); X (the step's input row, <= 8 features) is read per wave.
+// The record G [K][256] the separate weight-gradient kernel read back (64 MB written + 64 MB read per step at the
+// training batch, plus H_prev and X again) and that kernel's launch are gone.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int RPL> struct WgFrag { typedef u32x4 T; };
+template <> struct WgFrag<4> { typedef u32x2 T; };
+__device__ __forceinline__ f32x4 wg_mfma(const u32x4& a, const u32x4& b, f32x4 c) { return mfma_bf(a, b, c); }
+__device__ __forceinline__ f32x4 wg_mfma(const u32x2& a, const u32x2& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
 
 // RPL = sample rows per lane: 4 = one workgroup per 16-sample tile; 2 = one workgroup per HALF tile (8 samples, the
 // rows r in {2h, 2h+1} of every lane's four): the matrix products keep their 16-row shape (the unused rows of the
@@ -359,6 +383,23 @@ template <int RPL>
 __device__ __forceinline__ void store_rows(float* p, const RowVec<RPL>& x) {
     if constexpr (RPL == 4) *reinterpret_cast<f32x4*>(p) = (f32x4){x.v[0], x.v[1], x.v[2], x.v[3]};
     else *reinterpret_cast<f32x2*>(p) = (f32x2){x.v[0], x.v[1]};
+}
+
+// the step's RPL values of one operand -> slot POS of its three bf16 planes (weight gradients, above)
+template <int RPL, int POS>
+__device__ __forceinline__ void wg_put(typename WgFrag<RPL>::T (&f)[3], const RowVec<RPL>& v) {
+    unsigned p[3][RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) split3(v[r], p[0][r], p[1][r], p[2][r]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        if constexpr (RPL == 2) {
+            f[pl][POS] = (p[pl][0] >> 16) | p[pl][1];
+        } else {
+            f[pl][0] = (p[pl][0] >> 16) | p[pl][1];
+            f[pl][1] = (p[pl][2] >> 16) | p[pl][3];
+        }
+    }
 }
 
 template <int RPL>
@@ -471,13 +512,56 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
     // ---- BPTT ----------------------------------------------------------------------------
     // The saved activations of the steps ahead are fetched while the current step's MFMA chain runs, so the
     // recurrence never waits on HBM/L2 latency.
-    struct StepIn { RowVec<RPL> rg, zg, ng, hn, hprev, sc; };
+    struct StepIn { RowVec<RPL> rg, zg, ng, hn, hprev, sc, xv; };
     StepIn sb0, sb1, sb2;                  // three steps of saved activations in flight (HBM latency > one step)
     const float* scp = s.sv_score + row0 + rbase;
+    const float* xp = s.sv_x + (row0 + rbase) * 8 + (jl & 7);
+    const float xkeep = jl < 8 ? 1.0f : 0.0f;                 // X operand columns 8..15 are zero
+    // weight-gradient operands under assembly and accumulators (see above): A = deltas of this wave's units
+    // (drp, dzp, ghn = dnp * r, dnp), B = h_{t-1} / the input row
+    typedef typename WgFrag<RPL>::T Frag;
+    Frag fa[4][3], fb[3], fx[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fa[g][pl] = Frag{};
+        fb[pl] = Frag{}; fx[pl] = Frag{};
+    }
+    f32x4 whh[3][4], wih[3];                                  // [drp | dzp | ghn] x hidden column tile; [drp | dzp | dnp] x X
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) whh[g][nt] = f32x4{0, 0, 0, 0};
+        wih[g] = f32x4{0, 0, 0, 0};
+    }
+    float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};                 // column sums of drp, dzp, dnp, ghn (bias gradients)
+    // one group of products: every wave's H operand from LDS (this wave's own from registers), six cross terms smallest first,
+    // consecutive instructions on different accumulators
+    auto wg_flush = [&](int hbuf) {
+        const Frag* hx = reinterpret_cast<const Frag*>(&L.hx[hbuf][0]) + lane;
+#define WG_TERM(ACC, A, AP, B, BP) ACC = wg_mfma(A[AP], B[BP], ACC);
+#define WG_SIX(STMT) STMT(2, 0) STMT(0, 2) STMT(1, 1) STMT(1, 0) STMT(0, 1) STMT(0, 0)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            Frag hb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) hb[pl] = hx[(nt * 3 + pl) * 64];
+#define WG_HH(AP, BP) WG_TERM(whh[0][nt], fa[0], AP, hb, BP) WG_TERM(whh[1][nt], fa[1], AP, hb, BP) WG_TERM(whh[2][nt], fa[2], AP, hb, BP)
+            WG_SIX(WG_HH)
+#undef WG_HH
+        }
+#define WG_IH(AP, BP) WG_TERM(wih[0], fa[0], AP, fx, BP) WG_TERM(wih[1], fa[1], AP, fx, BP) WG_TERM(wih[2], fa[3], AP, fx, BP)
+        WG_SIX(WG_IH)
+#undef WG_IH
+#undef WG_SIX
+#undef WG_TERM
+    };
     auto fetch = [&](StepIn& d, int t) {
         d.rg = rec(s.sv_r, t); d.zg = rec(s.sv_z, t); d.ng = rec(s.sv_n, t); d.hn = rec(s.sv_hn, t);
         d.hprev = rec(s.sv_h, t);                              // block t = h_{t-1}
         d.sc = load_rows<RPL>(scp + (int64_t)t * Bp);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) d.xv[r] = xp[((int64_t)t * Bp + r) * 8];       // feature jl & 7 of the step's input rows
     };
     fetch(sb0, S - 1);
     if (S >= 2) fetch(sb1, S - 2);
@@ -494,8 +578,15 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
     // data-dependent branch around its memory operations: the compiler's wait-count bookkeeping stays exact across the
     // loop (with a conditional prefetch it fell back to waiting for ALL outstanding loads at the top of every iteration,
     // i.e. for the records requested one step earlier - the full memory latency, every third step).
-    auto bptt_step = [&](int t, StepIn& cur, auto last_tag) {
+    // POS (RPL 2 only): the step's slot in the weight-gradient operands; the products are issued behind slot 2
+    auto bptt_step = [&](int t, StepIn& cur, auto last_tag, auto pos_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int POS = RPL == 2 ? decltype(pos_tag)::value : 0;
+        constexpr bool FLUSH = RPL == 4 || POS == 2;
+        static_assert(!LAST || FLUSH, "step 0 closes a group");
+        // two exchange buffers where flushes follow each other step by step (a fast wave must not overwrite its H
+        // operand while a slow one still reads the previous flush's): every step of RPL 4, step 0 behind step 1 of RPL 2
+        const int hbuf = RPL == 4 ? (t & 1) : (LAST ? 1 : 0);
         const int buf = t & 1;
         // this step's record moves to locals and the buffer's next occupant starts its trip at once (below step 3: a
         // harmless re-read of record 0 into a buffer that is done): the longer the distance to its use, the less of
@@ -540,12 +631,35 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
             zs[r] = zg; dhs[r] = dh;
         }
         hnext = in.hprev;
-        {                                                      // d(pre-activation) record for the weight gradients
-            float* gb = s.bw_g + ((((int64_t)t * ntile + tile) * 4) * 4 + wq) * 256 + lo4;
-            store_rows<RPL>(gb, g0); store_rows<RPL>(gb + 1024, g1);
-            store_rows<RPL>(gb + 2048, g2); store_rows<RPL>(gb + 3072, g3);
+        {                                                      // the step's slot of the weight-gradient operands
+            if constexpr (LAST && RPL == 2) {                  // step 0 is a group of its own: slots 0, 1 are empty
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { fa[g][pl][0] = 0u; fa[g][pl][1] = 0u; }
+                    fb[pl][0] = 0u; fb[pl][1] = 0u; fx[pl][0] = 0u; fx[pl][1] = 0u;
+                }
+            }
+            wg_put<RPL, POS>(fa[0], g0); wg_put<RPL, POS>(fa[1], g1); wg_put<RPL, POS>(fa[2], g3); wg_put<RPL, POS>(fa[3], g2);
+            wg_put<RPL, POS>(fb, in.hprev);
+            RowVec<RPL> xm;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                xm[r] = in.xv[r] * xkeep;
+                bsum[0] += g0[r]; bsum[1] += g1[r]; bsum[2] += g2[r]; bsum[3] += g3[r];
+            }
+            wg_put<RPL, POS>(fx, xm);
+            if constexpr (FLUSH) {
+                Frag* hx = reinterpret_cast<Frag*>(&L.hx[hbuf][0]) + lane;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) hx[(wq * 3 + pl) * 64] = fb[pl];
+            }
         }
-        if constexpr (LAST) return;                            // dh_{-1} is not needed
+        if constexpr (LAST) {                                  // dh_{-1} is not needed
+            __syncthreads();
+            wg_flush(hbuf);
+            return;
+        }
         __syncthreads();
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         {
@@ -577,6 +691,7 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
 #undef GB_TERM
 #undef GB_LOAD
         }
+        if constexpr (FLUSH) wg_flush(hbuf);                   // behind the chain's products: nothing of this step waits for them
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
             dhc[r] = dhs[r] * zs[r] + (acc0[r] + acc1[r]);
@@ -586,24 +701,57 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
         using No = std::integral_constant<bool, false>;
         using Yes = std::integral_constant<bool, true>;
         // steps S-1 .. 1 in groups of three (the buffers keep their roles), the (S-1) % 3 odd ones first, then step 0
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using P2 = std::integral_constant<int, 2>;
         int t = S - 1;
         const int rem = t % 3;
-        if (rem == 1) {
-            bptt_step(t, sb0, No{});
+        if (rem == 1) {                                        // a leading group of one or two steps: the operands start as zeros
+            bptt_step(t, sb0, No{}, P2{});
             StepIn x = sb0; sb0 = sb1; sb1 = sb2; sb2 = x;
             t -= 1;
         } else if (rem == 2) {
-            bptt_step(t, sb0, No{});
-            bptt_step(t - 1, sb1, No{});
+            bptt_step(t, sb0, No{}, P1{});
+            bptt_step(t - 1, sb1, No{}, P2{});
             StepIn x = sb2; sb2 = sb1; sb1 = sb0; sb0 = x;
             t -= 2;
         }
         for (; t >= 3; t -= 3) {
-            bptt_step(t, sb0, No{});
-            bptt_step(t - 1, sb1, No{});
-            bptt_step(t - 2, sb2, No{});
+            bptt_step(t, sb0, No{}, P0{});
+            bptt_step(t - 1, sb1, No{}, P1{});
+            bptt_step(t - 2, sb2, No{}, P2{});
         }
-        bptt_step(0, sb0, Yes{});
+        bptt_step(0, sb0, Yes{}, P2{});
+    }
+    // ---- weight-gradient partials of this workgroup, in the layout of three reduction jobs ([M*N + M] each):
+    // accumulator register r of lane (jl, q) is [gate row 16 wq + 4q + r of the tile][column jl]
+    {
+        const int F = s.F;
+        float* Pih = s.bw_wih + (int64_t)hb * (G3 * F + G3);
+        float* Prz = s.bw_wrz + (int64_t)hb * (128 * E + 128);
+        float* Pn = s.bw_wn + (int64_t)hb * (E * E + E);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int u = 16 * wq + 4 * q + r;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                Prz[u * E + 16 * nt + jl] = whh[0][nt][r];
+                Prz[(E + u) * E + 16 * nt + jl] = whh[1][nt][r];
+                Pn[u * E + 16 * nt + jl] = whh[2][nt][r];
+            }
+            if (jl < F) {
+                Pih[u * F + jl] = wih[0][r];
+                Pih[(E + u) * F + jl] = wih[1][r];
+                Pih[(2 * E + u) * F + jl] = wih[2][r];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { bsum[g] += __shfl_xor(bsum[g], 16, 64); bsum[g] += __shfl_xor(bsum[g], 32, 64); }
+        if (q == 0) {
+            Pih[G3 * F + j] = bsum[0]; Pih[G3 * F + E + j] = bsum[1]; Pih[G3 * F + 2 * E + j] = bsum[2];
+            Prz[128 * E + j] = bsum[0]; Prz[128 * E + E + j] = bsum[1];
+            Pn[E * E + j] = bsum[3];
+        }
     }
     daw += __shfl_xor(daw, 16, 64); daw += __shfl_xor(daw, 32, 64);
     dab += __shfl_xor(dab, 16, 64); dab += __shfl_xor(dab, 32, 64);
@@ -613,10 +761,20 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
     if (wq == 0 && lane == 0) pa[64] = dab;
 }
 
+// workgroup `bid` of one group of windows: its (tile, slot), or with args.serial every slot of its tile in turn
+template <int RPL>
+__device__ __forceinline__ void gru_bwd_group(GruBwdLds& L, const GruBwdArgs& args, int bid) {
+    const int n = args.serial ? args.nslots : 1;
+    for (int i = 0; i < n; ++i) {
+        gru_bwd_body<RPL>(L, args, args.serial ? bid * args.nslots + i : bid);
+        __syncthreads();
+    }
+}
+
 template <int RPL>
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
     __shared__ __attribute__((aligned(16))) GruBwdLds L;
-    gru_bwd_body<RPL>(L, args, (int)blockIdx.x);
+    gru_bwd_group<RPL>(L, args, (int)blockIdx.x);
 }
 // Two groups of windows with their own tile modes in ONE launch (workgroups [0, na) the first): the learner's long
 // window on 8-sample tiles next to the short ones on 16-sample tiles.  As two launches on two streams they ran side
@@ -625,8 +783,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs args) {
 template <int RA, int RB>
 __global__ __launch_bounds__(256) void gru_bwd_pair_kernel(GruBwdArgs a, GruBwdArgs b, int na) {
     __shared__ __attribute__((aligned(16))) GruBwdLds L;
-    if ((int)blockIdx.x < na) gru_bwd_body<RA>(L, a, (int)blockIdx.x);
-    else gru_bwd_body<RB>(L, b, (int)blockIdx.x - na);
+    if ((int)blockIdx.x < na) gru_bwd_group<RA>(L, a, (int)blockIdx.x);
+    else gru_bwd_group<RB>(L, b, (int)blockIdx.x - na);
 }
 
 struct GruPrepBwdArgs { const float* whh[3]; u32x4* out[3]; };
@@ -659,13 +817,14 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st) {
     for (int i = 0; i < a.nslots; ++i) MCTSQ_CHECK(a.slot[i].S <= MAX_SEQ, "window too long");
     for (int i = 0; i < a.nslots; ++i)
         MCTSQ_CHECK(a.slot[i].wprep_t && ((uintptr_t)a.slot[i].wprep_t & 15) == 0, "GRU backward needs the transposed prepared weights");
-    if (a.half) hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3((unsigned)(a.Bp / TILE * 2 * a.nslots)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(gru_bwd_kernel<4>, dim3((unsigned)(a.Bp / TILE * a.nslots)), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)gru_bwd_blocks(a));
+    if (a.half) hipLaunchKernelGGL(gru_bwd_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gru_bwd_kernel<4>, grid, dim3(256), 0, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
 
-int64_t gru_bwd_blocks(const GruBwdArgs& a) { return a.Bp / TILE * (a.half ? 2 : 1) * a.nslots; }
+int64_t gru_bwd_blocks(const GruBwdArgs& a) { return a.Bp / TILE * (a.half ? 2 : 1) * (a.serial ? (a.nslots > 0) : a.nslots); }
 
 int launch_gru_bwd_pair(const GruBwdArgs& a, const GruBwdArgs& b, hipStream_t st) {
     if (a.nslots == 0) return launch_gru_bwd(b, st);
@@ -685,157 +844,6 @@ int launch_gru_bwd_pair(const GruBwdArgs& a, const GruBwdArgs& b, hipStream_t st
     else if (a.half) hipLaunchKernelGGL((gru_bwd_pair_kernel<2, 4>), grid, dim3(256), 0, st, a, b, na);
     else if (b.half) hipLaunchKernelGGL((gru_bwd_pair_kernel<4, 2>), grid, dim3(256), 0, st, a, b, na);
     else hipLaunchKernelGGL((gru_bwd_pair_kernel<4, 4>), grid, dim3(256), 0, st, a, b, na);
-    MCTSQ_HIP(hipGetLastError());
-    return 0;
-}
-
-// ================================================== GRU weight gradients (fused, one pass per slot)
-// Block = 4 waves, `rows` k-rows of one slot (k = step * Bp + row), walked in slabs of 32 rows = two 16-row tile
-// blocks of the lane-major records G (4 gates) and H_prev, staged through LDS TRANSPOSED ([column][k], row stride
-// 36: a record's float4 = four consecutive k of one column = one 16-byte LDS write, and the MFMA operand reads --
-// lane (jl, q) takes [column base + jl][4 ks + q] -- hit 64 distinct banks); the next slab is in flight while the
-// current one feeds the MFMAs.  Per 4-row k-step wave w issues 15 MFMAs: [dr|dz] columns 32w..32w+31 against the
-// four H tiles and the X tile (10), dn columns 128+16w.. against X (1), dn*r columns 192+16w.. against the four H
-// tiles (4); the A fragments' column sums (bias gradients) ride along as VALU adds.
-constexpr int GW_KT = 32, GW_LDT = 36;
-constexpr int GW_GT = 256 * GW_LDT, GW_HT = 64 * GW_LDT, GW_XS = GW_KT * 16, GW_BUF = GW_GT + GW_HT + GW_XS;
-__global__ __launch_bounds__(256) void gru_wgrad_kernel(GruWgradArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float gw_lds[];           // [2][GW_BUF]
-    int si = 0;
-    for (int k = 1; k < args.nslots; ++k)
-        if ((int)blockIdx.x >= args.slot[k].blk0) si = k;
-    const GruWgradSlot& S = args.slot[si];
-    const int split = blockIdx.x - S.blk0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, jl = lane & 15, q = lane >> 4;
-    const int k0 = split * S.rows, k1 = min(k0 + S.rows, S.K), F = S.F;
-    // staging roles: float4 number tid + 256 p of the slab's G blocks (p < 8) and H blocks (p < 2); X one float
-    const int xr = tid >> 3, xc = tid & 7;
-    f32x4 rg[8], rh[2];
-    float rx;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    auto fetch = [&](int kb) {                               // slab starting at k-row kb (a multiple of 32) -> registers
-        const int64_t b0 = kb >> 4;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int f = tid + 256 * p, blk = f >> 10;
-            rg[p] = kb + 16 * blk < k1 ? *reinterpret_cast<const f32x4*>(S.G + (b0 + blk) * 4096 + (int64_t)(f & 1023) * 4) : z4;
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int f = tid + 256 * p, blk = f >> 8;
-            rh[p] = kb + 16 * blk < k1 ? *reinterpret_cast<const f32x4*>(S.Hprev + (b0 + blk) * 1024 + (int64_t)(f & 255) * 4) : z4;
-        }
-        const int k_ = kb + xr;
-        rx = k_ < k1 ? S.X[(int64_t)k_ * 8 + xc] : 0.0f;
-    };
-    auto stash = [&](int buf) {
-        float* Lb = gw_lds + buf * GW_BUF;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int f = tid + 256 * p, blk = f >> 10, rem = f & 1023, ln = rem & 63;
-            const int col = (rem >> 8) * 64 + ((rem >> 6) & 3) * 16 + (ln & 15);
-            *reinterpret_cast<f32x4*>(&Lb[col * GW_LDT + blk * 16 + 4 * (ln >> 4)]) = rg[p];
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int f = tid + 256 * p, blk = f >> 8, rem = f & 255, ln = rem & 63;
-            const int col = (rem >> 6) * 16 + (ln & 15);
-            *reinterpret_cast<f32x4*>(&Lb[GW_GT + col * GW_LDT + blk * 16 + 4 * (ln >> 4)]) = rh[p];
-        }
-        Lb[GW_GT + GW_HT + xr * 16 + xc] = rx;
-    };
-    // X tile columns 8..15 stay zero in both buffers
-    for (int i = tid; i < 2 * GW_KT * 8; i += 256) {
-        const int b = i / (GW_KT * 8), rr = (i >> 3) % GW_KT, cc = i & 7;
-        gw_lds[b * GW_BUF + GW_GT + GW_HT + rr * 16 + 8 + cc] = 0.0f;
-    }
-    f32x4 arz[2][5], an = {0, 0, 0, 0}, anr[4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < 5; ++t) arz[m][t] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) anr[t] = f32x4{0, 0, 0, 0};
-    float bs0 = 0.f, bs1 = 0.f, bsn = 0.f, bsr = 0.f;
-    fetch(k0);
-    stash(0);
-    __syncthreads();
-    int buf = 0;
-    for (int kb = k0; kb < k1; kb += GW_KT) {
-        const bool more = kb + GW_KT < k1;
-        if (more) fetch(kb + GW_KT);
-        const float* Lb = gw_lds + buf * GW_BUF;
-        const float* ga = Lb + jl * GW_LDT + q;                  // A operands: [column][k]
-        const float* hb = Lb + GW_GT + jl * GW_LDT + q;          // H tiles:    [unit][k]
-        const float* xb = Lb + GW_GT + GW_HT + q * 16 + jl;      // X tile:     [k][feature]
-#pragma unroll
-        for (int ks = 0; ks < GW_KT / 4; ++ks) {
-            const int ko = 4 * ks;
-            const float a0 = ga[(32 * w) * GW_LDT + ko], a1 = ga[(32 * w + 16) * GW_LDT + ko];
-            const float a2 = ga[(128 + 16 * w) * GW_LDT + ko], a3 = ga[(192 + 16 * w) * GW_LDT + ko];
-            const float h0 = hb[ko], h1 = hb[16 * GW_LDT + ko], h2 = hb[32 * GW_LDT + ko], h3 = hb[48 * GW_LDT + ko];
-            const float xv = xb[ko * 16];
-            arz[0][0] = mfma16(a0, h0, arz[0][0]); arz[1][0] = mfma16(a1, h0, arz[1][0]); anr[0] = mfma16(a3, h0, anr[0]);
-            arz[0][1] = mfma16(a0, h1, arz[0][1]); arz[1][1] = mfma16(a1, h1, arz[1][1]); anr[1] = mfma16(a3, h1, anr[1]);
-            arz[0][2] = mfma16(a0, h2, arz[0][2]); arz[1][2] = mfma16(a1, h2, arz[1][2]); anr[2] = mfma16(a3, h2, anr[2]);
-            arz[0][3] = mfma16(a0, h3, arz[0][3]); arz[1][3] = mfma16(a1, h3, arz[1][3]); anr[3] = mfma16(a3, h3, anr[3]);
-            arz[0][4] = mfma16(a0, xv, arz[0][4]); arz[1][4] = mfma16(a1, xv, arz[1][4]); an = mfma16(a2, xv, an);
-            bs0 += a0; bs1 += a1; bsn += a2; bsr += a3;
-        }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-    // ---- partials in the three WJob layouts: D register r of lane (jl, q) is [m = 4q + r][n = jl] ----
-    float* Pih = S.wp_ih + (int64_t)split * (G3 * F + G3);
-    float* Prz = S.wp_rz + (int64_t)split * (128 * E + 128);
-    float* Pn = S.wp_n + (int64_t)split * (E * E + E);
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int mm = 32 * w + 16 * m + 4 * q + r;                      // row of [dr|dz]
-#pragma unroll
-            for (int t = 0; t < 4; ++t) Prz[mm * E + 16 * t + jl] = arz[m][t][r];
-            if (jl < F) Pih[mm * F + jl] = arz[m][4][r];
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int mm = 16 * w + 4 * q + r;
-        if (jl < F) Pih[(128 + mm) * F + jl] = an[r];                        // dn rows of W_ih
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Pn[mm * E + 16 * t + jl] = anr[t][r];
-    }
-    // bias column sums: fold the four k groups; lane jl of group 0 holds column jl of the fragment
-    bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
-    bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
-    bsn += __shfl_xor(bsn, 16, 64); bsn += __shfl_xor(bsn, 32, 64);
-    bsr += __shfl_xor(bsr, 16, 64); bsr += __shfl_xor(bsr, 32, 64);
-    if (q == 0) {
-        Pih[G3 * F + 32 * w + jl] = bs0; Pih[G3 * F + 32 * w + 16 + jl] = bs1; Pih[G3 * F + 128 + 16 * w + jl] = bsn;
-        Prz[128 * E + 32 * w + jl] = bs0; Prz[128 * E + 32 * w + 16 + jl] = bs1;
-        Pn[E * E + 16 * w + jl] = bsr;
-    }
-}
-
-void gru_wgrad_geometry(int64_t K, int* rows, int* nsplit) {
-    int64_t r = (K + 255) / 256;                              // at most 256 blocks per slot
-    r = (r + GW_KT - 1) / GW_KT * GW_KT;
-    if (r < 160) r = 160;
-    *rows = (int)r;
-    *nsplit = (int)((K + r - 1) / r);
-}
-
-int launch_gru_wgrad(const GruWgradArgs& a, hipStream_t st) {
-    if (a.nslots == 0 || a.nblocks == 0) return 0;
-    const size_t lds = 2 * GW_BUF * sizeof(float);            // 94 KB
-    static bool once = false;
-    if (!once) {
-        MCTSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_wgrad_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        once = true;
-    }
-    hipLaunchKernelGGL(gru_wgrad_kernel, dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

@@ -46,13 +46,14 @@ int launch_head_bwd(const HeadBwdArgs& a, hipStream_t st);
 constexpr int64_t HEAD_PREP_BWD_BYTES = (int64_t)(8 * 3 + 8 * 4 * 3 + 12 * 4 * 3) * 64 * 16;
 int launch_head_prepare_bwd(const float* w0, const float* w1, const float* w2, int A, void* prep, hipStream_t st);
 
-// ---- GRU-attention backward: LayerNorm, attention pooling, BPTT (deltas only) ----
+// ---- GRU-attention backward: LayerNorm, attention pooling, BPTT and the weight gradients (per-workgroup partials) ----
 struct GruBwdArgs {
     GruSlot slot[3];
     int nslots;
     int64_t Bp;
     const float* dfeat;         // [Bp][192]
     int half;                   // 1: one workgroup per 8 samples (gru_bwd_kernel<2>), bw_aw partials [Bp/8][65]
+    int serial;                 // 1: one workgroup walks all slots of its tile, one after the other (fewer, longer workgroups)
 };
 // W_hh [192][64] as the B operand of the BPTT product delta [16 x 192] . W_hh: u32x4 [wave 4][K chunk 6][plane 3][lane 64],
 // lane (jl, q) of wave w holds W_hh[32c + 8q .. +7][16w + jl]; GRU_PREP_BYTES per slot
@@ -61,23 +62,6 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t st);
 int64_t gru_bwd_blocks(const GruBwdArgs& a);
 // both groups of windows in one launch (each with its own tile mode); either may be empty
 int launch_gru_bwd_pair(const GruBwdArgs& a, const GruBwdArgs& b, hipStream_t st);
-
-// ---- GRU weight gradients, all of one slot's big contractions in one pass over the saved tensors ----
-// dW_ih = [dr|dz|dn]^T X, dW_hh[0:128] = [dr|dz]^T H_prev, dW_hh[128:192] = (dn*r)^T H_prev and the
-// bias column sums, from G [K][256] = dr|dz|dn|dn*r (gru_bwd_kernel), H_prev [K][64], X [K][8].
-// Every block owns `rows` consecutive k-rows and writes one partial in the layout of three WJobs
-// ([M*N + M] each), reduced in block order by wgrad_reduce_kernel (bitwise reproducible).
-struct GruWgradSlot {
-    const float *G, *Hprev, *X;
-    float *wp_ih, *wp_rz, *wp_n;   // [nsplit][192*F + 192], [nsplit][128*64 + 128], [nsplit][64*64 + 64]
-    int K, F, rows, nsplit, blk0;
-};
-struct GruWgradArgs {
-    GruWgradSlot slot[3];
-    int nslots, nblocks;
-};
-void gru_wgrad_geometry(int64_t K, int* rows, int* nsplit);
-int launch_gru_wgrad(const GruWgradArgs& a, hipStream_t st);
 
 // ---- Conv-attention backward (enc_conv.hip) and gas/EUA MLP backward (enc_mlp.hip) ----
 struct ConvBwdArgs {

@@ -29,10 +29,9 @@ struct Carver {
 
 struct SlotPlan {                      // float offsets; which fields are used depends on the kind
     int64_t score, stat, pool, x, dsc, p;
-    int64_t h, r, z, n, hn, g;          // gru
-    int64_t wp_ih, wp_rz, wp_n, wp_aw, wp_ln;  // gru: partials of the fused weight-gradient kernel / of gru_bwd_kernel
+    int64_t h, r, z, n, hn;             // gru
+    int64_t wp_ih, wp_rz, wp_n, wp_aw, wp_ln;  // gru: per-workgroup partials of gru_bwd_kernel (weight gradients, score Linear, LayerNorm)
     int64_t wt;                         // gru: W_hh as split-bf16 B fragments of the BPTT product (gru_prepare_bwd_kernel)
-    int gw_rows, gw_nsplit;
     int64_t c_h1, c_h2, c_d2, c_d1;     // conv
     int64_t m_x, m_m0, m_d1, m_d0;      // mlp
     // transformer: [l] per layer
@@ -88,13 +87,13 @@ int make_plan(const NetLayout& L, int64_t B, TrainPlan* P) {
             g.h = c.take((S + 1) * Bp * E);
             g.r = c.take(K * E); g.z = c.take(K * E); g.n = c.take(K * E); g.hn = c.take(K * E);
             g.score = c.take(K); g.stat = c.take(Bp * 4); g.pool = c.take(Bp * E); g.x = c.take(K * 8);
-            g.g = c.take(K * 256); g.dsc = c.take(K); g.p = c.take(Bp * E);
+            g.dsc = c.take(K); g.p = c.take(Bp * E);
             MCTSQ_CHECK(K < ((int64_t)1 << 31), "batch too large");
-            gru_wgrad_geometry(K, &g.gw_rows, &g.gw_nsplit);
-            g.wp_ih = c.take((int64_t)g.gw_nsplit * (G3 * e.F + G3));
-            g.wp_rz = c.take((int64_t)g.gw_nsplit * (128 * E + 128));
-            g.wp_n = c.take((int64_t)g.gw_nsplit * (E * E + E));
-            g.wp_aw = c.take(Bp / TILE * 2 * 65);       // per workgroup of the GRU backward (8- or 16-sample tiles)
+            const int64_t nwg = Bp / TILE * 2;           // per workgroup of the GRU backward (8- or 16-sample tiles)
+            g.wp_ih = c.take(nwg * (G3 * e.F + G3));
+            g.wp_rz = c.take(nwg * (128 * E + 128));
+            g.wp_n = c.take(nwg * (E * E + E));
+            g.wp_aw = c.take(nwg * 65);
             g.wp_ln = c.take(Bp / TILE * 2 * E);
             g.wt = c.take(GRU_PREP_BYTES / (int64_t)sizeof(float));
             pf += 2 * job_partial_floats(E, 0, Bp);
@@ -478,7 +477,8 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         SlotSave& v = sv[s];
         v.score = ws + g.score; v.stat = ws + g.stat; v.pool = ws + g.pool; v.x = ws + g.x; v.dsc = ws + g.dsc;
         v.p = ws + g.p;
-        v.h = ws + g.h; v.r = ws + g.r; v.z = ws + g.z; v.n = ws + g.n; v.hn = ws + g.hn; v.g = ws + g.g;
+        v.h = ws + g.h; v.r = ws + g.r; v.z = ws + g.z; v.n = ws + g.n; v.hn = ws + g.hn;
+        v.wih = ws + g.wp_ih; v.wrz = ws + g.wp_rz; v.wn = ws + g.wp_n;
         v.aw = ws + g.wp_aw; v.ln = ws + g.wp_ln;
         v.c_h1 = ws + g.c_h1; v.c_h2 = ws + g.c_h2; v.c_d2 = ws + g.c_d2; v.c_d1 = ws + g.c_d1;
         v.m_x = ws + g.m_x; v.m_m0 = ws + g.m_m0; v.m_d1 = ws + g.m_d1; v.m_d0 = ws + g.m_d0;
@@ -545,9 +545,6 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
     // 5./6. encoder backward (deltas) and weight gradients (every tensor is one or a few K-contractions), on two
     // lanes: `jbA` holds the products that need only the head's deltas, `jbB` those behind the encoder backward
     JobBuilder jbA(ws), jbB(ws);
-    GruWgradArgs gwMain, gwSide;
-    memset(&gwMain, 0, sizeof(gwMain));
-    memset(&gwSide, 0, sizeof(gwSide));
     int gru_half[2] = {0, 0};                                 // tile mode of the GRU backward per lane (caller's, helper)
     bool merged = false;                                      // both groups of GRU windows in ONE launch on the caller's stream
     // the longest GRU window stays on the caller's stream, the others go to the helper stream
@@ -582,6 +579,11 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             if (2 * nt * (gbMain.nslots + gbSide.nslots) <= 256) gbMain.half = gbSide.half = 1;
             else if (nt * (2 * gbMain.nslots + gbSide.nslots) <= 256) gbMain.half = 1;
             gru_half[0] = gbMain.half; gru_half[1] = gbSide.half;
+            // The backward workgroups take a SIMD's whole register file each (weight-gradient accumulators), so nothing
+            // of the helper lane (the head's weight-gradient products, the priority write-back) shares a CU with them.
+            // Where the launch would cover the chip, the short windows of a tile are walked by ONE workgroup (still
+            // shorter than the long window's chain) and a quarter of the CUs stays free for that lane.
+            if (gbSide.nslots > 1 && gru_bwd_blocks(gbMain) + gru_bwd_blocks(gbSide) > 192) gbSide.serial = 1;
         }
         // One wave of workgroups for both groups together: ONE launch on the caller's stream (and one for their weight
         // gradients below): the groups run side by side either way, and the first helper lane with its launches, its
@@ -639,30 +641,19 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
         const SlotPlan& g = P.slot[s];
         const int64_t K = (int64_t)e.S * Bp;
         if (e.kind == MCTSQ_ENC_GRU) {
-            const float* G = ws + g.g;
-            const float* Hprev = ws + g.h;                    // block t = h_{t-1}
-            // W_ih [192][F] + b_ih: delta (r|z|n) x x_t;  W_hh rows r,z + b_hh[0:128]: delta (r|z) x h_{t-1};
-            // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1} -- one fused pass (gru_wgrad_kernel),
-            // reduced here in block order
-            {
-                GruWgradArgs& gw = (s == long_slot || merged) ? gwMain : gwSide;
-                GruWgradSlot& w = gw.slot[gw.nslots++];
-                w.G = G; w.Hprev = Hprev; w.X = ws + g.x; w.K = (int)K; w.F = e.F; w.rows = g.gw_rows;
-                w.nsplit = g.gw_nsplit; w.blk0 = gw.nblocks;
-                w.wp_ih = ws + g.wp_ih; w.wp_rz = ws + g.wp_rz; w.wp_n = ws + g.wp_n;
-                gw.nblocks += g.gw_nsplit;
-            }
-            if (jbB.add_external(g.wp_ih - P.partials, G3, e.F, g.gw_nsplit, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
-            if (jbB.add_external(g.wp_rz - P.partials, 2 * E, E, g.gw_nsplit, e.gru.whh, E, 1, e.gru.bhh)) return -1;
-            if (jbB.add_external(g.wp_n - P.partials, E, E, g.gw_nsplit, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E))
+            // Everything of this encoder arrives as per-workgroup partials of gru_bwd_kernel, reduced here in workgroup
+            // order: W_ih [192][F] + b_ih: delta (r|z|n) x x_t;  W_hh rows r,z + b_hh[0:128]: delta (r|z) x h_{t-1};
+            // W_hh rows n + b_hh[128:192]: (delta_n * r) x h_{t-1}
+            const int nwg = (int)(Bp / TILE) * (gru_half[s == long_slot ? 0 : 1] ? 2 : 1);
+            if (jbB.add_external(g.wp_ih - P.partials, G3, e.F, nwg, e.gru.wih, e.F, 1, e.gru.bih)) return -1;
+            if (jbB.add_external(g.wp_rz - P.partials, 2 * E, E, nwg, e.gru.whh, E, 1, e.gru.bhh)) return -1;
+            if (jbB.add_external(g.wp_n - P.partials, E, E, nwg, e.gru.whh + 2 * E * E, E, 1, e.gru.bhh + 2 * E))
                 return -1;
-            // attention score Linear(64,1): d(score) x h_t, per-tile partials written by gru_bwd_kernel
-            if (jbB.add_external(g.wp_aw - P.partials, 1, E, (int)(Bp / TILE) * (gru_half[s == long_slot ? 0 : 1] ? 2 : 1),
-                                 e.gru.aw, E, 1, e.gru.ab)) return -1;
-            // LayerNorm weight: per-workgroup column sums of dfeat * xhat written by gru_bwd_kernel (a launch of its own
-            // for the long window's sums sat on the critical path); bias: column sums of dfeat over the batch
-            if (jbB.add_external(g.wp_ln - P.partials, E, 0, (int)(Bp / TILE) * (gru_half[s == long_slot ? 0 : 1] ? 2 : 1),
-                                 -1, 0, 0, e.gru.lnw)) return -1;
+            // attention score Linear(64,1): d(score) x h_t
+            if (jbB.add_external(g.wp_aw - P.partials, 1, E, nwg, e.gru.aw, E, 1, e.gru.ab)) return -1;
+            // LayerNorm weight: column sums of dfeat * xhat (a launch of its own for the long window's sums sat on the
+            // critical path); bias: column sums of dfeat over the batch
+            if (jbB.add_external(g.wp_ln - P.partials, E, 0, nwg, -1, 0, 0, e.gru.lnw)) return -1;
             if (addA(ws + P.dfeat, FEAT, s * E, nullptr, 0, 0, E, 0, Bp, -1, 0, 0, e.gru.lnb)) return -1;
         } else if (e.kind == MCTSQ_ENC_CONV) {
             // conv weights [out][in][3]: one contraction per tap against the time-shifted input
@@ -725,15 +716,9 @@ static int dqn_grad_enqueue(const NetLayout& L, const TrainPlan& P, const SideSt
             return -1;
     }
     MCTSQ_HIP(hipEventRecord(side->join3, side->st2));
-    // first helper lane: the short windows' weight gradients (their backward is already queued there), unless both
-    // groups went to the caller's stream together
-    if (gwSide.nslots > 0) {
-        if (launch_gru_wgrad(gwSide, side->st)) return -1;
-        side_used = true;
-    }
+    // first helper lane: the short windows' backward, unless both groups went to the caller's stream together
     if (side_used) MCTSQ_HIP(hipEventRecord(side->join2, side->st));
-    // caller's stream: the long window's (or all windows') weight gradients and everything else behind the encoder backward
-    if (launch_gru_wgrad(gwMain, st)) return -1;
+    // caller's stream: everything else behind the encoder backward
     for (int i = 0; i < jbB.nlists; ++i)
         if (launch_wgrad(jbB.lists[i], ws, ws + P.partials, st)) return -1;
     if (side_used) MCTSQ_HIP(hipStreamWaitEvent(st, side->join2, 0));
