@@ -346,6 +346,9 @@ struct GruBwdLds {
 // their H operands through LDS (12 KB per flush); X (the step's input row, <= 8 features) is read per wave.
 // The record G [K][256] the separate weight-gradient kernel read back (64 MB written + 64 MB read per step at the
 // training batch, plus H_prev and X again) and that kernel's launch are gone.
+#ifndef MCTSQ_WG_TERMS
+#define MCTSQ_WG_TERMS 6        // cross terms per weight-gradient product (build parameter for measurements: 3 = two planes, 0 = none)
+#endif
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int RPL> struct WgFrag { typedef u32x4 T; };
@@ -540,7 +543,13 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
     auto wg_flush = [&](int hbuf) {
         const Frag* hx = reinterpret_cast<const Frag*>(&L.hx[hbuf][0]) + lane;
 #define WG_TERM(ACC, A, AP, B, BP) ACC = wg_mfma(A[AP], B[BP], ACC);
+#if MCTSQ_WG_TERMS == 6
 #define WG_SIX(STMT) STMT(2, 0) STMT(0, 2) STMT(1, 1) STMT(1, 0) STMT(0, 1) STMT(0, 0)
+#elif MCTSQ_WG_TERMS == 3
+#define WG_SIX(STMT) STMT(1, 0) STMT(0, 1) STMT(0, 0)
+#else
+#define WG_SIX(STMT)
+#endif
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             Frag hb[3];

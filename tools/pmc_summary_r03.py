@@ -100,7 +100,7 @@ if dom:
     sq["kernel"] = "gru3_head_fwd_kernel<false>"
 json.dump(sq, open(os.path.join(ROOT, "profiles", "r03_sq_counters.json"), "w"), indent=1)
 for name in ("gru3_head_fwd_kernel<false>", "gru3_head_fwd_pair_kernel", "gru_bwd_pair_kernel<2, 4>", "tf_ffn_pair_kernel<4>",
-             "tf_attn_pair_kernel", "conv_enc_fwd_kernel<false>", "tf_ffn_bwd_kernel", "gru_wgrad_kernel"):
+             "tf_attn_pair_kernel", "conv_enc_fwd_kernel<false>", "tf_ffn_bwd_kernel", "head_bwd_bf16_kernel"):
     r = sq["kernels"].get(name, {})
     t = traffic["kernels"].get(name, {})
     print(f"{name:32s} mfma_busy {r.get('mfma_busy_frac')}  wait {r.get('wait_any_frac')}  lds_wait {r.get('lds_wait_frac')}  "
