@@ -461,7 +461,11 @@ def main():
             step_flops = 4 * (enc_fl + head_fl) * Bg           # policy fwd + 2 x bwd + target fwd
             rows = Bg if world == 1 else bcap
             act_bytes = sum(S * rows * 64 * 4 * 5 for S in spec.seq)      # r, z, n, W_hn h, h per GRU step: written, read back
-            step_bytes = 2 * act_bytes + sum(S * rows * 256 * 4 * 2 for S in spec.seq) + 2 * 364 * rows + 16 * spec.n_flat * 4
+            # + the per-workgroup weight-gradient partials of the GRU backward (one workgroup per 8 rows of the longest
+            # window, per 16 rows of the others; ~12.7 k floats each, written and read by the reduction), the batch
+            # rows in and out of the sampler, parameters / moments / target / gradient through the optimizer
+            wg = sum((rows // 8 if S == max(spec.seq) else rows // 16) * (192 * 8 + 192 + 128 * 65 + 64 * 65) for S in spec.seq)
+            step_bytes = 2 * act_bytes + 2 * 4 * wg + 2 * 364 * rows + 16 * spec.n_flat * 4
             ach = step_flops / (twall / tsteps) / 1e12
             return {"metric": "PER-DQN train steps/sec (gru/gru/gru, 1M-entry sum-tree replay per rank, "
                               f"global batch {Bg})", "value": tsteps / twall, "unit": "train steps/s",

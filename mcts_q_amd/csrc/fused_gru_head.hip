@@ -6,6 +6,7 @@
 // workgroup barrier, so the shorter windows fill the gaps the long one's gate math and h exchange
 // leave.  Waves 0-3 then fetch the head's weight fragments straight into VGPRs while group 1 finishes;
 // the feature rows never leave LDS and the head needs no second launch.
+#include <cstdlib>
 #include "gru_core.hpp"
 #include "head_core.hpp"
 
@@ -32,13 +33,15 @@ struct FusedLds {
 #endif
 };
 
-template <bool SAVE>
+// RPL = 4: workgroup `tile` = one 16-sample tile; RPL = 2: one 8-sample half tile (gru_core.hpp), chosen by the host for
+// batches whose 16-sample tiles would leave half the CUs idle
+template <bool SAVE, int RPL>
 __device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga, const HeadArgs& ha, int tile) {
     // the wave index (and everything derived from it: group, unit block, head tile) lives in scalar registers
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3, gtid = tid & 255;
     const int jl = lane & 15, q = lane >> 4;
-    const int64_t row0 = (int64_t)tile * TILE;
+    const int64_t row0 = (int64_t)tile * (4 * RPL);
     GruLds& G = L.g[grp];
     // group 0 takes the longest window; group 1 runs the other two back to back on the same SIMDs (issue
     // priorities were measured to make no difference: the two waves of a SIMD share it evenly)
@@ -48,7 +51,7 @@ __device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga
     const int sb = big == 2 ? 1 : 2;
 
     STAMP(0);
-    GruWave<SAVE> g;
+    GruWave<SAVE, RPL> g;
     g.bind(lane, wq);
     // One copy of the window code serves both groups and both of group 1's windows (a loop, not two
     // inlined call sites): half the instruction footprint, and the second window runs from a warm
@@ -89,7 +92,7 @@ __device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga
     }
     // The GRU weight registers are dead from here on: the head's fragments take their place and travel under the
     // last LayerNorm (head_core.hpp).
-    HeadWave<SAVE> hd;
+    HeadWave<SAVE, RPL> hd;
     hd.load(ha, lane, wave);
     {
         const GruSlot& s = ga.slot[si];
@@ -111,21 +114,30 @@ __device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga
 #endif
 }
 
-template <bool SAVE>
+template <bool SAVE, int RPL>
 __global__ __launch_bounds__(512) void gru3_head_fwd_kernel(GruFwdArgs ga, HeadArgs ha) {
     __shared__ __attribute__((aligned(16))) FusedLds L;
-    gru3_head_tile<SAVE>(L, ga, ha, blockIdx.x);
+    gru3_head_tile<SAVE, RPL>(L, ga, ha, blockIdx.x);
 }
 
 // The learner's two forwards in ONE launch: workgroups [0, n0) run the policy network on s with the activation records
 // kept, the others the target network on s' (dqn_per.py:455-463).  Same code per tile as the two separate launches;
 // what goes away is the second launch, the helper-stream hand-off around it and the cross-queue wait before the head
 // backward.
+template <int RPL>
 __global__ __launch_bounds__(512) void gru3_head_fwd_pair_kernel(GruFwdArgs ga0, HeadArgs ha0, GruFwdArgs ga1, HeadArgs ha1,
                                                                  int n0) {
     __shared__ __attribute__((aligned(16))) FusedLds L;
-    if ((int)blockIdx.x < n0) gru3_head_tile<true>(L, ga0, ha0, blockIdx.x);
-    else gru3_head_tile<false>(L, ga1, ha1, (int)blockIdx.x - n0);
+    if ((int)blockIdx.x < n0) gru3_head_tile<true, RPL>(L, ga0, ha0, blockIdx.x);
+    else gru3_head_tile<false, RPL>(L, ga1, ha1, (int)blockIdx.x - n0);
+}
+
+// 8-sample workgroups while they still fit the chip as one wave of workgroups (one per CU: 512 threads at 256 registers)
+static bool half_tiles(int64_t tiles16) {
+    static const int force = getenv("MCTSQ_FWD_RPL") ? atoi(getenv("MCTSQ_FWD_RPL")) : 0;   // 2 / 4: measurements and tests
+    if (force == 2) return true;
+    if (force == 4) return false;
+    return 2 * tiles16 <= 256;
 }
 
 #ifdef MCTSQ_STAMPS
@@ -148,9 +160,16 @@ int launch_gru3_head_fwd(const GruFwdArgs& ga, const HeadArgs& ha, bool save, hi
     if (check_gru_args(ga)) return -1;
     MCTSQ_CHECK(fused_gru_head_applicable(ga, ha), "fused GRU+head kernel needs gru/gru/gru and a 192-128-128-A head");
     MCTSQ_CHECK(ha.wprep, "fused GRU+head kernel needs the prepared head weights");
-    dim3 grid((unsigned)(ga.Bp / TILE));
-    if (save) hipLaunchKernelGGL(gru3_head_fwd_kernel<true>, grid, dim3(512), 0, st, ga, ha);
-    else hipLaunchKernelGGL(gru3_head_fwd_kernel<false>, grid, dim3(512), 0, st, ga, ha);
+    const int64_t tiles = ga.Bp / TILE;
+    if (half_tiles(tiles)) {
+        const dim3 grid((unsigned)(2 * tiles));
+        if (save) hipLaunchKernelGGL((gru3_head_fwd_kernel<true, 2>), grid, dim3(512), 0, st, ga, ha);
+        else hipLaunchKernelGGL((gru3_head_fwd_kernel<false, 2>), grid, dim3(512), 0, st, ga, ha);
+    } else {
+        const dim3 grid((unsigned)tiles);
+        if (save) hipLaunchKernelGGL((gru3_head_fwd_kernel<true, 4>), grid, dim3(512), 0, st, ga, ha);
+        else hipLaunchKernelGGL((gru3_head_fwd_kernel<false, 4>), grid, dim3(512), 0, st, ga, ha);
+    }
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }
@@ -162,7 +181,10 @@ int launch_gru3_head_fwd_pair(const GruFwdArgs& ga0, const HeadArgs& ha0, const 
                 "paired forward needs gru/gru/gru, a 192-128-128-A head and prepared weights");
     MCTSQ_CHECK(ga0.B > 0 && ga1.B > 0, "paired forward: empty batch");
     const int n0 = (int)(ga0.Bp / TILE), n1 = (int)(ga1.Bp / TILE);
-    hipLaunchKernelGGL(gru3_head_fwd_pair_kernel, dim3((unsigned)(n0 + n1)), dim3(512), 0, st, ga0, ha0, ga1, ha1, n0);
+    if (half_tiles(n0 + n1))
+        hipLaunchKernelGGL(gru3_head_fwd_pair_kernel<2>, dim3((unsigned)(2 * (n0 + n1))), dim3(512), 0, st, ga0, ha0, ga1, ha1, 2 * n0);
+    else
+        hipLaunchKernelGGL(gru3_head_fwd_pair_kernel<4>, dim3((unsigned)(n0 + n1)), dim3(512), 0, st, ga0, ha0, ga1, ha1, n0);
     MCTSQ_HIP(hipGetLastError());
     return 0;
 }

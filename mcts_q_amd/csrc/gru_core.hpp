@@ -53,17 +53,30 @@ __device__ __forceinline__ void group_sync(unsigned* ctr, unsigned target, int l
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <bool SAVE>
+// RPL = sample rows per lane.  4: the group advances a 16-sample tile, lane (jl, q) holds rows 4q..4q+3 of its unit.
+// 2: an 8-sample HALF tile (sample si of the eight sits in matrix row 4 (si / 2) + si % 2, i.e. lane (jl, q) holds
+// samples 2q, 2q+1 as its rows r = 0, 1; matrix rows 4q+2, 4q+3 carry whatever LDS holds and nobody reads their
+// outputs: a row of a matrix product depends on that row of the A operand only).  The matrix instructions are the
+// same; every per-(row, unit) vector / transcendental instruction, LDS write and record store is issued for two rows
+// instead of four.  For batches whose 16-sample tiles leave half the CUs idle (the learner's B = 1024: 2 x 64 tiles;
+// the search's leaf batches) twice the workgroups at half the vector work each shorten the per-step chain.  The
+// records keep their layout (a half tile owns a contiguous half of every lane-major block, as in gru_bwd_kernel<2>).
+template <bool SAVE, int RPL = 4>
 struct GruWave {
+    static_assert(RPL == 4 || RPL == 2, "rows per lane");
+    static constexpr int TR = 4 * RPL;                        // samples per group
+    // sample (relative to the group's first row) of this lane's row r, and the matrix row of sample i
+    __device__ __forceinline__ int srow(int r) const { return RPL == 4 ? 4 * q + r : 2 * q + r; }
+    static __device__ __forceinline__ int mrow(int i) { return RPL == 4 ? i : 4 * (i >> 1) + (i & 1); }
     u32x4 whi[3][2], wlo[3][2];     // 2^sh W_hh[g*64 + j][32c + 8q .. +7], gate g, K chunk c, split-fp16
     float esr, esz, esn, invn;      // exp2-argument constants of the three gates with 2^-k of unit j folded in; 2^-k_n
     float wir[2], wiz[2], win[2];   // W_ih[g*64 + j][q (+4)], zero padded
     f32x4 brv, bzv, binv, bhnv;     // gate biases replicated over the 4 accumulator rows: the accumulators START from them
     float awj, abl;                 // score weight of unit j (log2 units); the score bias rides on one lane's product
-    float hh[2][4];                 // hh[t & 1] = h_t (this wave's 16 units, rows 4q..4q+3)
-    float att[4], mrun[4], lrun[4];
+    float hh[2][RPL];               // hh[t & 1] = h_t (this wave's 16 units, the lane's RPL rows)
+    float att[RPL], mrun[RPL], lrun[RPL];
     bool bounded;                   // scores provably inside +-60 (log2 units): softmax without the running max
-    float pooled[4], mean[4], rstd[4];
+    float pooled[RPL], mean[RPL], rstd[RPL];
     float xin[4], pdead;            // staged window elements in flight (stage_issue -> stage_commit); weight of a dead fold
     float ab2, lnwj, lnbj;          // score bias (log2 units), LayerNorm scale / shift of unit j: fetched with the weights
     int lane, wq, jl, q, j, FP;
@@ -74,9 +87,14 @@ struct GruWave {
     // reads the step keeps in flight.
     float *rp_r, *rp_z, *rp_n, *rp_hn, *rp_h, *rp_sc;
     int64_t rec_stride, sc_stride;
+    int rec_lo;                     // this lane's float offset inside a 256-float record block
     __device__ __forceinline__ void bind_records(const GruSlot& s, int64_t row0, int64_t Bp) {
         if (!SAVE) return;
         const int64_t ub0 = ((row0 / TILE) * 4 + wq) * 256;
+        // RPL 2: samples 8 half + 2q + {0, 1} of the 16-sample tile = rows 2 (q & 1) + {0, 1} of record lane
+        // jl + 16 (2 half + q / 2): one 8-byte store, a wave's 64 lanes one contiguous 512-byte half of the block
+        const int half = (int)((row0 >> 3) & 1);
+        rec_lo = RPL == 4 ? lane * 4 : (jl + 16 * (2 * half + (q >> 1))) * 4 + 2 * (q & 1);
         rp_r = s.sv_r + ub0; rp_z = s.sv_z + ub0; rp_n = s.sv_n + ub0; rp_hn = s.sv_hn + ub0;
         rp_h = s.sv_h + ub0 + Bp * E;
         rp_sc = s.sv_score + row0;
@@ -142,7 +160,7 @@ struct GruWave {
     }
     __device__ __forceinline__ void init_state() {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             hh[0][r] = 0.0f; hh[1][r] = 0.0f; att[r] = 0.0f;
             lrun[r] = bounded ? -2.0f * pdead : 0.0f;
             mrun[r] = bounded ? 0.0f : -1e30f;
@@ -166,7 +184,7 @@ struct GruWave {
     // buffer 0 = 0.  The tile's 16 windows are one contiguous run of 16*S*Fd floats; the first 1024 of
     // them (all of them for every shipped window shape) travel through xin[].
     __device__ __forceinline__ void stage_issue(const GruSlot& s, int gtid, int64_t row0, int64_t B) {
-        const int SFd = s.S * s.Fd, n = TILE * SFd;
+        const int SFd = s.S * s.Fd, n = TR * SFd;
         const float* src = s.x + row0 * (int64_t)SFd;
         const int64_t lim = (B - row0) * (int64_t)SFd;        // floats present in the batch
 #pragma unroll
@@ -180,7 +198,7 @@ struct GruWave {
     __device__ __forceinline__ void stage_commit(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t B, int64_t Bp,
                                                  bool first = true) {
         const int S = s.S, F = s.F, Fd = s.Fd, SFd = S * Fd, sh = FP == 8 ? 3 : 2;
-        const int n = TILE * SFd;                             // <= 16 * 32 * 8 = 4096
+        const int n = TR * SFd;                               // <= 16 * 32 * 8 = 4096
         // everything that does not need the loaded elements first
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
@@ -190,20 +208,20 @@ struct GruWave {
         // columns Fd .. FP-1: time features of the non-_per flavour, then zero padding
         const int npad = FP - Fd, Snp = S * npad;
         const float inv_snp = 1.0f / (float)max(Snp, 1), inv_np = 1.0f / (float)max(npad, 1);
-        for (int idx = gtid; idx < TILE * Snp; idx += 256) {
+        for (int idx = gtid; idx < TR * Snp; idx += 256) {
             const int i = div_small(idx, Snp, inv_snp), rem = idx - i * Snp, t = div_small(rem, npad, inv_np);
             const int f = Fd + rem - t * npad;
-            L.xs[i * XLD + (t << sh) + f] = (f < F && row0 + i < B) ? time_feature(s.tf, t, f - Fd) : 0.0f;
+            L.xs[mrow(i) * XLD + (t << sh) + f] = (f < F && row0 + i < B) ? time_feature(s.tf, t, f - Fd) : 0.0f;
         }
-        if (SAVE)
-            for (int idx = gtid; idx < TILE * E; idx += 256) s.sv_h[row0 * E + idx] = 0.0f;   // h_{-1}
+        if (SAVE)                                             // h_{-1}: the tile's whole block 0 (RPL 2: from both halves)
+            for (int idx = gtid; idx < TILE * E; idx += 256) s.sv_h[(row0 / TILE) * (int64_t)(TILE * E) + idx] = 0.0f;
         const float inv_sfd = 1.0f / (float)SFd, inv_fd = 1.0f / (float)Fd;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = u * 256 + gtid;
             if (e < n) {
                 const int i = div_small(e, SFd, inv_sfd), rem = e - i * SFd, t = div_small(rem, Fd, inv_fd);
-                L.xs[i * XLD + (t << sh) + rem - t * Fd] = xin[u];
+                L.xs[mrow(i) * XLD + (t << sh) + rem - t * Fd] = xin[u];
             }
         }
         for (int e0 = 1024; e0 < n; e0 += 1024) {             // longer windows than any shipped configuration
@@ -214,7 +232,7 @@ struct GruWave {
                 const int e = e0 + u * 256 + gtid;
                 if (e < n) {
                     const int i = div_small(e, SFd, inv_sfd), rem = e - i * SFd, t = div_small(rem, Fd, inv_fd);
-                    L.xs[i * XLD + (t << sh) + rem - t * Fd] = e < lim ? src[e] : 0.0f;
+                    L.xs[mrow(i) * XLD + (t << sh) + rem - t * Fd] = e < lim ? src[e] : 0.0f;
                 }
             }
         }
@@ -223,10 +241,10 @@ struct GruWave {
     __device__ __forceinline__ void save_window(const GruSlot& s, GruLds& L, int gtid, int64_t row0, int64_t Bp) {
         // sv_x[(t * Bp + row) * 8 + f]: one (step, row) pair per thread and pass, its eight floats as two 16-byte stores
         // (index math is shifts only; the element-wise form divided by S * 8 thirteen times per thread)
-        const int n = TILE * s.S;
+        const int n = TR * s.S;
         for (int idx = gtid; idx < n; idx += 256) {
-            const int t = idx >> 4, i = idx & 15;
-            const float* x = &L.xs[i * XLD + t * (FP == 8 ? 8 : 4)];
+            const int t = RPL == 4 ? idx >> 4 : idx >> 3, i = idx & (TR - 1);
+            const float* x = &L.xs[mrow(i) * XLD + t * (FP == 8 ? 8 : 4)];
             f32x4 a = {x[0], x[1], x[2], x[3]}, b = {0, 0, 0, 0};
             if (FP == 8) b = (f32x4){x[4], x[5], x[6], x[7]};       // xs is zero padded up to FP features
             float* dst = s.sv_x + ((int64_t)t * Bp + row0 + i) * 8;
@@ -242,10 +260,10 @@ struct GruWave {
     // visible behind sync t+1).  spart is indexed by step parity: step t writes parity (t-1)&1 and
     // reads parity t&1; a wave cannot run more than one sync ahead, and its reads are complete
     // before it arrives (the release fence drains lgkmcnt), so the two never collide.
-    __device__ __forceinline__ void publish(GruLds& L, const float (&hv)[4], int par) {
-        float4 ps;
+    __device__ __forceinline__ void publish(GruLds& L, const float (&hv)[RPL], int par) {
+        float4 ps = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         ps.x = row16_sum(fmaf(awj, hv[0], abl)); ps.y = row16_sum(fmaf(awj, hv[1], abl));
-        ps.z = row16_sum(fmaf(awj, hv[2], abl)); ps.w = row16_sum(fmaf(awj, hv[3], abl));
+        if constexpr (RPL == 4) { ps.z = row16_sum(fmaf(awj, hv[2], abl)); ps.w = row16_sum(fmaf(awj, hv[3], abl)); }
         // one lane per row group stores; the others write their (identical) sums to a dump slot of
         // their own, which keeps the instruction stream branch-free for the interleaving below
         float* dst = jl == 0 ? &L.spart[par][wq][4 * q] : &L.dump[wq][lane * 4];
@@ -264,7 +282,7 @@ struct GruWave {
     // fold hv (= h_t of this wave's units, whose score parts are in sp) into the running sums.
     // BND: plain sums of exp2(score) (mrun stays 0); otherwise the online form with a running maximum.
     template <bool BND>
-    __device__ __forceinline__ void attend(const GruSlot& s, const float4 (&sp)[4], const float (&hv)[4], bool live,
+    __device__ __forceinline__ void attend(const GruSlot& s, const float4 (&sp)[4], const float (&hv)[RPL], bool live,
                                            int t, int64_t row0, int64_t Bp) {
         const float p[4][4] = {{sp[0].x, sp[0].y, sp[0].z, sp[0].w}, {sp[1].x, sp[1].y, sp[1].z, sp[1].w},
                                {sp[2].x, sp[2].y, sp[2].z, sp[2].w}, {sp[3].x, sp[3].y, sp[3].z, sp[3].w}};
@@ -272,14 +290,17 @@ struct GruWave {
             const f32x4 sc4 = {(p[0][0] + p[1][0]) + (p[2][0] + p[3][0]), (p[0][1] + p[1][1]) + (p[2][1] + p[3][1]),
                                (p[0][2] + p[1][2]) + (p[2][2] + p[3][2]), (p[0][3] + p[1][3]) + (p[2][3] + p[3][3])};
             if (live) {                                       // wave-uniform; live folds come in step order 0, 1, 2, ...
-                if (wq == 0 && jl == 0) *reinterpret_cast<f32x4*>(rp_sc + 4 * q) = sc4;
+                if (wq == 0 && jl == 0) {
+                    if constexpr (RPL == 4) *reinterpret_cast<f32x4*>(rp_sc + 4 * q) = sc4;
+                    else *reinterpret_cast<f32x2*>(rp_sc + 2 * q) = (f32x2){sc4[0], sc4[1]};
+                }
                 rp_sc += sc_stride;
             }
         }
 #if MCTSQ_GRU_PK
         if (BND) {                                            // the common path, on packed pairs of rows
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
+            for (int pp = 0; pp < RPL / 2; ++pp) {
                 const f32x2 sc = ((f32x2){p[0][2 * pp], p[0][2 * pp + 1]} + (f32x2){p[1][2 * pp], p[1][2 * pp + 1]}) +
                                  ((f32x2){p[2][2 * pp], p[2][2 * pp + 1]} + (f32x2){p[3][2 * pp], p[3][2 * pp + 1]});
                 const f32x2 e = {fast_exp2(sc.x), fast_exp2(sc.y)};
@@ -291,7 +312,7 @@ struct GruWave {
         }
 #endif
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             float sc = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
             if (BND) {
                 const float e = fast_exp2(sc);
@@ -379,10 +400,10 @@ struct GruWave {
         accn = mfma_h(ah[0], whi[2][0], accn);  accm = mfma_h(ah[1], whi[2][1], accm);
         // Gate arithmetic on PAIRS of rows (packed fp32 instructions process two values per lane at the rate of one):
         // the step is bound by vector + transcendental issue once the matrix part is halved
-        float rg[4], zg[4];
+        float rg[RPL], zg[RPL];
 #if MCTSQ_GRU_PK
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < RPL / 2; ++p) {
             const f32x2 er = (f32x2){accr[2 * p], accr[2 * p + 1]} * esr, ez = (f32x2){accz[2 * p], accz[2 * p + 1]} * esz;
             const f32x2 dr = (f32x2){fast_exp2(er.x), fast_exp2(er.y)} + 1.0f, dz = (f32x2){fast_exp2(ez.x), fast_exp2(ez.y)} + 1.0f;
             rg[2 * p] = fast_rcp(dr.x); rg[2 * p + 1] = fast_rcp(dr.y);
@@ -390,7 +411,7 @@ struct GruWave {
         }
 #else
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             rg[r] = fast_rcp(1.0f + fast_exp2(esr * accr[r]));      // sigmoid of 2^-k accr
             zg[r] = fast_rcp(1.0f + fast_exp2(esz * accz[r]));
         }
@@ -400,15 +421,19 @@ struct GruWave {
         // vector address math.  Each field leaves as soon as it exists (r, z here, under the n gate's products; n, W_hn h
         // and h at the end): five stores back to back from every wave of the CU at once queued up in the memory pipe
         // and the last wave's issue stalled behind them on the step's critical path.
-        const int lo = lane * 4;
+        const int lo = rec_lo;
+        auto put = [&](float* dst, const float (&v)[RPL]) {   // the lane's RPL rows of one unit: one 16- or 8-byte store
+            if constexpr (RPL == 4) *reinterpret_cast<f32x4*>(dst) = (f32x4){v[0], v[1], v[2], v[3]};
+            else *reinterpret_cast<f32x2*>(dst) = (f32x2){v[0], v[1]};
+        };
         if (SAVE) {
-            *reinterpret_cast<f32x4*>(rp_r + lo) = (f32x4){rg[0], rg[1], rg[2], rg[3]};
-            *reinterpret_cast<f32x4*>(rp_z + lo) = (f32x4){zg[0], zg[1], zg[2], zg[3]};
+            put(rp_r + lo, rg);
+            put(rp_z + lo, zg);
         }
-        f32x4 svn, svhn, svh;
+        float svn[RPL], svhn[RPL], svh[RPL];
 #if MCTSQ_GRU_PK
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < RPL / 2; ++p) {
             const f32x2 hn = (f32x2){accn[2 * p], accn[2 * p + 1]} + (f32x2){accm[2 * p], accm[2 * p + 1]};   // 2^k (W_hn h + b_hn)
             const f32x2 rg2 = {rg[2 * p], rg[2 * p + 1]}, zg2 = {zg[2 * p], zg[2 * p + 1]};
             const f32x2 an = ((f32x2){acci[2 * p], acci[2 * p + 1]} + rg2 * hn) * esn;
@@ -430,7 +455,7 @@ struct GruWave {
         }
 #else
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             const int i = 4 * q + r;
             const float hn = accn[r] + accm[r];                                   // 2^k (W_hn h + b_hn)
             const float ng = 1.0f - 2.0f * fast_rcp(1.0f + fast_exp2(esn * (acci[r] + rg[r] * hn)));   // tanh of 2^-k (...)
@@ -444,9 +469,9 @@ struct GruWave {
         }
 #endif
         if (SAVE) {
-            *reinterpret_cast<f32x4*>(rp_n + lo) = svn;
-            *reinterpret_cast<f32x4*>(rp_hn + lo) = svhn;
-            *reinterpret_cast<f32x4*>(rp_h + lo) = svh;
+            put(rp_n + lo, svn);
+            put(rp_hn + lo, svhn);
+            put(rp_h + lo, svh);
             rp_r += rec_stride; rp_z += rec_stride; rp_n += rec_stride; rp_hn += rec_stride; rp_h += rec_stride;
         }
     }
@@ -459,10 +484,10 @@ struct GruWave {
     // in the middle of the LayerNorm (scratch round trips: ~4 us per window in the saving kernel).
     __device__ __forceinline__ void fin0(GruLds& L, const GruSlot& s, int64_t row0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RPL; ++r) {
             pooled[r] = att[r] / lrun[r];
             if (SAVE) {                                       // uniform base (scalar registers) + 32-bit lane offset
-                const int i = 4 * q + r;
+                const int i = srow(r);
                 (s.sv_pool + row0 * (int64_t)E)[(unsigned)(i * E + j)] = pooled[r];
                 if (wq == 0 && jl == 0) *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(i * 4)) = (f32x2){mrun[r], lrun[r]};
             }
@@ -476,8 +501,8 @@ struct GruWave {
     // (lnw, lnb: this window's lnwj / lnbj, read by the caller before a following window's init_weights)
     __device__ __forceinline__ void fin2(const GruSlot& s, GruLds& L, float* out, int ld, int64_t row0, float lnw, float lnb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * q + r;
+        for (int r = 0; r < RPL; ++r) {
+            const int i = 4 * q + r, si = srow(r);            // matrix row (LDS), sample (out, records)
             const float s0 = L.red[0][0][i], s1 = L.red[0][1][i], s2 = L.red[0][2][i], s3 = L.red[0][3][i];
             mean[r] = ((s0 + s1) + (s2 + s3)) * (1.0f / E);
             const float d0 = s0 * (1.0f / 16) - mean[r], d1 = s1 * (1.0f / 16) - mean[r];
@@ -485,9 +510,9 @@ struct GruWave {
             const float m2 = ((L.red[1][0][i] + L.red[1][1][i]) + (L.red[1][2][i] + L.red[1][3][i])) +
                              16.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             rstd[r] = 1.0f / sqrtf(m2 * (1.0f / E) + LN_EPS);
-            out[i * ld + j] = (pooled[r] - mean[r]) * rstd[r] * lnw + lnb;
+            out[si * ld + j] = (pooled[r] - mean[r]) * rstd[r] * lnw + lnb;
             if (SAVE && wq == 0 && jl == 0)
-                *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(i * 4 + 2)) = (f32x2){mean[r], rstd[r]};
+                *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(si * 4 + 2)) = (f32x2){mean[r], rstd[r]};
         }
     }
     // fin2 for a consumer that multiplies on the bf16 matrix instruction: the normalised feature goes to three
@@ -496,8 +521,8 @@ struct GruWave {
     __device__ __forceinline__ void fin2_split(const GruSlot& s, GruLds& L, unsigned short* planes, int pstride, int ld,
                                                int64_t row0, float lnw, float lnb, float* gfeats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * q + r;
+        for (int r = 0; r < RPL; ++r) {
+            const int i = 4 * q + r, si = srow(r);            // matrix row (LDS planes), sample (global rows)
             const float s0 = L.red[0][0][i], s1 = L.red[0][1][i], s2 = L.red[0][2][i], s3 = L.red[0][3][i];
             mean[r] = ((s0 + s1) + (s2 + s3)) * (1.0f / E);
             const float d0 = s0 * (1.0f / 16) - mean[r], d1 = s1 * (1.0f / 16) - mean[r];
@@ -513,8 +538,8 @@ struct GruWave {
             dst[pstride] = (unsigned short)(u1 >> 16);
             dst[2 * pstride] = (unsigned short)(u2 >> 16);
             if (SAVE) {
-                if (gfeats) (gfeats + row0 * (int64_t)FEAT)[(unsigned)(i * FEAT + j + s.out_col)] = v;
-                if (wq == 0 && jl == 0) *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(i * 4 + 2)) = (f32x2){mean[r], rstd[r]};
+                if (gfeats) (gfeats + row0 * (int64_t)FEAT)[(unsigned)(si * FEAT + j + s.out_col)] = v;
+                if (wq == 0 && jl == 0) *reinterpret_cast<f32x2*>(s.sv_stat + row0 * 4 + (unsigned)(si * 4 + 2)) = (f32x2){mean[r], rstd[r]};
             }
         }
     }

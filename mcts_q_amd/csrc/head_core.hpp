@@ -29,8 +29,11 @@ struct HeadLds {
     unsigned short apl[2][3][TILE * APL];    // hidden layers 0 and 1, same form
 };
 
-template <bool SAVE>
+// RPL (gru_core.hpp): 4 = a 16-row tile, lane row r is row 4q + r; 2 = an 8-row half tile whose row 2q + r sits in
+// matrix row 4q + r (r < 2): the products are the same, the per-row work behind them is done for the real rows only
+template <bool SAVE, int RPL = 4>
 struct HeadWave {
+    static __device__ __forceinline__ int srow(int q, int r) { return RPL == 4 ? 4 * q + r : 2 * q + r; }
     u32x4 hw[2][18], hw2[12];
     float hb[2], hb2;
 
@@ -79,14 +82,14 @@ struct HeadWave {
             for (int tt = 0; tt < 2; ++tt) {
                 const int col = 16 * (ht + 4 * tt) + jl;
     #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < RPL; ++r) {
                     const float v = apply_act(acc[tt][0][r] + acc[tt][1][r], ha.act);
                     unsigned u0, u1, u2;
                     split3(v, u0, u1, u2);
                     L.apl[0][0][(4 * q + r) * APL + col] = (unsigned short)(u0 >> 16);
                     L.apl[0][1][(4 * q + r) * APL + col] = (unsigned short)(u1 >> 16);
                     L.apl[0][2][(4 * q + r) * APL + col] = (unsigned short)(u2 >> 16);
-                    if (SAVE) ha.sv_act[0][(row0 + 4 * q + r) * (int64_t)128 + col] = v;
+                    if (SAVE) ha.sv_act[0][(row0 + srow(q, r)) * (int64_t)128 + col] = v;
                 }
             }
             // layer 0's fragments are dead: the output layer's take their registers and arrive while waves 4-7 run layer 1
@@ -111,14 +114,14 @@ struct HeadWave {
             for (int tt = 0; tt < 2; ++tt) {
                 const int col = 16 * (ht + 4 * tt) + jl;
     #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < RPL; ++r) {
                     const float v = apply_act(acc[tt][0][r] + acc[tt][1][r], ha.act);
                     unsigned u0, u1, u2;
                     split3(v, u0, u1, u2);
                     L.apl[1][0][(4 * q + r) * APL + col] = (unsigned short)(u0 >> 16);
                     L.apl[1][1][(4 * q + r) * APL + col] = (unsigned short)(u1 >> 16);
                     L.apl[1][2][(4 * q + r) * APL + col] = (unsigned short)(u2 >> 16);
-                    if (SAVE) ha.sv_act[1][(row0 + 4 * q + r) * (int64_t)128 + col] = v;
+                    if (SAVE) ha.sv_act[1][(row0 + srow(q, r)) * (int64_t)128 + col] = v;
                 }
             }
         }
@@ -145,9 +148,9 @@ struct HeadWave {
             // (lane position re-derived here: values computed at kernel entry would sit in registers across every loop)
             const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), jl = ln & 15, q = ln >> 4;
             const bool colok = jl < ha.A;
-            {
+            if (ht < RPL) {                                   // (a half tile has two real rows per lane: waves 0, 1)
                 const int r = ht;
-                const int64_t row = row0 + 4 * q + r;
+                const int64_t row = row0 + srow(q, r);
                 const float v = r == 0 ? acc0[0] + acc1[0] : r == 1 ? acc0[1] + acc1[1] : r == 2 ? acc0[2] + acc1[2] : acc0[3] + acc1[3];
                 const float best = row16_max_dpp(colok ? v : -INFINITY);
                 const float first = row16_min_dpp((colok && v == best) ? (float)jl : 99.0f);   // like torch.argmax
