@@ -370,3 +370,17 @@ def test_unprepared_gradient_entry_point_gives_the_same_bits():
                                  torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.equal(grad, g_ref) and torch.equal(loss, loss_ref) and torch.equal(td, abs_td)
+
+
+def test_half_tile_forward_and_gradient_are_bit_identical():
+    """The gru/gru/gru forward runs on 8-sample half tiles when 16-sample tiles would leave half the CUs idle
+    (fused_gru_head.hip: half_tiles).  Same arithmetic per row, so Q, argmax, priors, |td|, loss and the flat gradient
+    (i.e. every record the backward reads) must not change by a bit: tools/fwd_rpl_check.py runs both modes in child
+    processes (the mode is read once per process from MCTSQ_FWD_RPL) and compares the dumps."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fwd_rpl_check.py"), "21", "1000"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "B=21: identical" in r.stdout and "B=1000: identical" in r.stdout

@@ -18,8 +18,8 @@ spec = NetSpec.from_cfg(cfg)
 _, sd = seeded_net(cfg)
 g = torch.Generator().manual_seed(B)
 rows, nrows = torch.rand(B, 91, generator=g), torch.rand(B, 91, generator=g)
-from oracle import torch_ref
-s, s2 = torch_ref.split_state_rows(rows.numpy()), torch_ref.split_state_rows(nrows.numpy())
+split = lambda r: (r[:, :25].reshape(-1, 25, 1).contiguous(), r[:, 25:85].reshape(-1, 10, 6).contiguous(), r[:, 85:91].reshape(-1, 3, 2).contiguous())
+s, s2 = split(rows), split(nrows)
 net = DeviceQNet(spec).load_state_dict(sd)
 o = net.forward(s[0].cuda(), s[1].cuda(), s[2].cuda(), want_prior=True)
 q, vmax, am, prior = o["q"], o["vmax"], o["argmax"], o["prior"]
