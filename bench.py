@@ -173,9 +173,9 @@ def executed_pipe_peak(spec):
     return total / t, (c["fp16x3"] + c["bf16x6"]) / total
 
 
-DOMINANT_KERNEL = {"gru/gru/gru": "gru3_head_fwd_kernel<false>", "conv/conv/mlp": "conv_enc_fwd_kernel",
+DOMINANT_KERNEL = {"gru/gru/gru": "gru3_head_fwd_kernel<false, 4>", "conv/conv/mlp": "conv_enc_fwd_kernel",
                    "transformer/transformer/gru": "tf_ffn_pair_kernel"}
-TRAIN_DOMINANT = {"gru/gru/gru": "gru3_head_fwd_pair_kernel", "conv/conv/mlp": "conv_enc_bwd_kernel",
+TRAIN_DOMINANT = {"gru/gru/gru": "gru3_head_fwd_pair_kernel<2>", "conv/conv/mlp": "conv_enc_bwd_kernel",
                   "transformer/transformer/gru": "tf_ffn_bwd_kernel"}
 
 
@@ -380,7 +380,7 @@ def main():
     roofline = {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": prof["traffic"],
                 "traffic_source": prof["traffic_source"],
-                "kernel": "gru3_head_fwd_kernel<false>", "kernel_ms": k_ms,
+                "kernel": "gru3_head_fwd_kernel<false, 4>", "kernel_ms": k_ms,
                 "kernel_ms_single_launch_between_events": k_single_ms, "flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_GBs_algorithmic": alg_bytes / (k_ms * 1e-3) / 1e9,

@@ -62,10 +62,10 @@ for k in sorted(fetch):
     traffic["kernels"][short(k)] = {"FETCH_SIZE_KB_avg": fv, "WRITE_SIZE_KB_avg": wv, "launches": len(fetch[k]["FETCH_SIZE"]),
                                     "hbm_bytes_per_launch": hbm, "avg_us": us,
                                     "hbm_GBs": (hbm / (us * 1e-6) / 1e9) if us else None}
-dom = traffic["kernels"].get("gru3_head_fwd_kernel<false>")
+dom = traffic["kernels"].get("gru3_head_fwd_kernel<false, 4>")
 if dom:
     traffic["hbm_bytes_per_launch"] = dom["hbm_bytes_per_launch"]
-    traffic["kernel"] = "gru3_head_fwd_kernel<false>"
+    traffic["kernel"] = "gru3_head_fwd_kernel<false, 4>"
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), "w"), indent=1)
 
 s1, s2 = counters("pmc_sq1"), counters("pmc_sq2")
@@ -94,12 +94,12 @@ for k in sorted(s1):
         rec["lds_bank_conflict_frac"] = b.get("SQ_LDS_BANK_CONFLICT", 0.0) / b["SQ_LDS_IDX_ACTIVE"]
     rec["launches"] = len(next(iter(s1[k].values())))
     sq["kernels"][short(k)] = rec
-dom = sq["kernels"].get("gru3_head_fwd_kernel<false>")
+dom = sq["kernels"].get("gru3_head_fwd_kernel<false, 4>")
 if dom:
     sq["mfma_busy_frac"] = dom.get("mfma_busy_frac")
-    sq["kernel"] = "gru3_head_fwd_kernel<false>"
+    sq["kernel"] = "gru3_head_fwd_kernel<false, 4>"
 json.dump(sq, open(os.path.join(ROOT, "profiles", "r03_sq_counters.json"), "w"), indent=1)
-for name in ("gru3_head_fwd_kernel<false>", "gru3_head_fwd_pair_kernel", "gru_bwd_pair_kernel<2, 4>", "tf_ffn_pair_kernel<4>",
+for name in ("gru3_head_fwd_kernel<false, 4>", "gru3_head_fwd_pair_kernel<2>", "gru_bwd_pair_kernel<2, 4>", "tf_ffn_pair_kernel<4>",
              "tf_attn_pair_kernel", "conv_enc_fwd_kernel<false>", "tf_ffn_bwd_kernel", "head_bwd_bf16_kernel"):
     r = sq["kernels"].get(name, {})
     t = traffic["kernels"].get(name, {})
