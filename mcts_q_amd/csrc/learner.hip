@@ -349,6 +349,9 @@ struct GruBwdLds {
 #ifndef MCTSQ_WG_TERMS
 #define MCTSQ_WG_TERMS 6        // cross terms per weight-gradient product (build parameter for measurements: 3 = two planes, 0 = none)
 #endif
+#if MCTSQ_WG_TERMS != 6 && !defined(MCTSQ_MEASUREMENT_BUILD)
+#error "MCTSQ_WG_TERMS other than 6 gives inexact (3) or no (0) weight gradients: timing builds only, with -DMCTSQ_MEASUREMENT_BUILD"
+#endif
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int RPL> struct WgFrag { typedef u32x4 T; };
