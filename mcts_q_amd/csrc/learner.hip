@@ -541,8 +541,8 @@ __device__ __forceinline__ void gru_bwd_body(GruBwdLds& L, const GruBwdArgs& arg
         wih[g] = f32x4{0, 0, 0, 0};
     }
     float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};                 // column sums of drp, dzp, dnp, ghn (bias gradients)
-    // one group of products: every wave's H operand from LDS (this wave's own from registers), six cross terms smallest first,
-    // consecutive instructions on different accumulators
+    // one group of products: every wave's H operand from LDS (its own included: one code path for the four column tiles),
+    // six cross terms smallest first, consecutive instructions on different accumulators
     auto wg_flush = [&](int hbuf) {
         const Frag* hx = reinterpret_cast<const Frag*>(&L.hx[hbuf][0]) + lane;
 #define WG_TERM(ACC, A, AP, B, BP) ACC = wg_mfma(A[AP], B[BP], ACC);
