@@ -558,7 +558,7 @@ def main():
             res["tree_search"] = trees
         if configs is not None:
             res["configs"] = configs
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU path is timed beside the one-GPU run only
             res["cpu_baseline"] = cpu_baseline(cfg, ref_net, B, args.train_batch, args.replay)
         print(json.dumps(res), flush=True)
     if world > 1:
