@@ -77,8 +77,56 @@ def gen_trained(enc):
           "ref fp32 vs fp64 %.2e" % float((q.double() - q64).abs().max() / q64.abs().max()), "largest drift", big)
 
 
+def gen_trained_std(enc, act):
+    """The non-`_per` flavour (src/mctsq_config_dqn.py: time features appended inside forward, hard target copy) with
+    the `tanh` head: trained_std_<enc>_<act>.npz, same keys except Q64 - that module's forward casts to float32 in its
+    NumPy round trip (:563-587), so the reference cannot be evaluated in float64; the tests use the fp64 oracle there."""
+    model = g1.build_model(g1.ref_std, "std", enc, act, batch_size=BATCH, capacity=2048, learning_starts=10)
+    for grp in model.optimizer.param_groups:
+        grp["lr"] = LR
+    model.policy_net.eval()
+    init = g1.sd_to_np(model.policy_net.state_dict())
+    rng = np.random.RandomState(2025)
+    obs = [g1.make_obs(rng) for _ in range(N_PUSH + 1)]
+    for i in range(N_PUSH):
+        a = int(rng.randint(5))
+        o = obs[i]
+        r = float(3.0 * o["Elec_Price"][12] - 2.0 * o["T_CAT"][-1] * (a >= 3) + o["Gas_Price"][1] * (a == 2)
+                  + 0.1 * rng.standard_normal())
+        model.replay_buffer.push(o, a, r, obs[i + 1], bool(rng.random_sample() < 0.05))
+    losses = []
+    for i in range(N_UPDATES):
+        losses.append(float(model.update()))
+        if i % 50 == 49:
+            model.update_target_network()
+    net = model.policy_net
+    sd = g1.sd_to_np(net.state_dict())
+    g = torch.Generator().manual_seed(4322)
+    B = 64
+    price, process, gas = torch.rand(B, 25, 1, generator=g), torch.rand(B, 10, 6, generator=g), torch.rand(B, 3, 2, generator=g)
+    with torch.no_grad():
+        q = net(price, process, gas)
+    out = {"sd/" + k: v for k, v in sd.items()}
+    out.update(price=price.numpy(), process=process.numpy(), gas=gas.numpy(), Q=q.numpy(),
+               vmax=q.max(1)[0].numpy(), argmax=q.argmax(1).numpy(), prior=torch.softmax(q, -1).numpy(),
+               losses=np.array(losses))
+    drift = {k: float(np.abs(sd[k] - init[k]).max() / max(np.abs(init[k]).max(), 1e-12)) for k in sd}
+    cfg = dict(flavor="std", price=enc[0], process=enc[1], gas=enc[2], act=act, updates=N_UPDATES, lr=LR,
+               batch=BATCH, seed=g1.SEED, torch=torch.__version__, drift=drift)
+    out["cfg"] = np.array(json.dumps(cfg))
+    name = "trained_std_" + "_".join(enc) + "_" + act + ".npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    big = sorted(drift.items(), key=lambda kv: -kv[1])[:3]
+    print("wrote", name, "loss %.4f -> %.4f" % (losses[0], losses[-1]), "max|Q| %.3f" % float(q.abs().max()),
+          "largest drift", big)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     os.chdir(g1.REF)
-    for enc in (("gru", "gru", "gru"), ("conv", "conv", "mlp"), ("transformer", "transformer", "gru")):
-        gen_trained(enc)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("", "per"):
+        for enc in (("gru", "gru", "gru"), ("conv", "conv", "mlp"), ("transformer", "transformer", "gru")):
+            gen_trained(enc)
+    if only in ("", "std"):
+        gen_trained_std(("gru", "gru", "gru"), "tanh")

@@ -61,10 +61,15 @@ def test_oracle_forward_on_trained_weights(path):
     ~1e-12, the torch restatement its fp32 Q bit for bit."""
     z, cfg = load_case(path)
     sd = {k[3:]: z[k] for k in z.files if k.startswith("sd/")}
-    assert len(TRAINED_FILES) == 3 and max(cfg["drift"].values()) > 1.0      # the weights did move
+    assert len(TRAINED_FILES) >= 4 and max(cfg["drift"].values()) > 1.0      # the weights did move
     q64 = qnet_numpy.q_forward(sd, cfg, z["price"], z["process"], z["gas"], np.float64)
-    scale = np.abs(z["Q64"]).max()
-    assert np.abs(q64 - z["Q64"]).max() <= 1e-10 * scale
+    scale = np.abs(z["Q"]).max()
+    if "Q64" in z.files:
+        assert np.abs(q64 - z["Q64"]).max() <= 1e-10 * scale
+    else:
+        # the non-_per module casts to float32 inside its forward (time-feature round trip): no fp64 evaluation of the
+        # reference exists, the fp64 oracle must sit within fp32 rounding of the reference's fp32 Q
+        assert cfg["flavor"] == "std" and np.abs(q64 - z["Q"]).max() <= 2e-6 * scale
     with torch.no_grad():
         q32 = torch_ref.RefQNet.from_state_dict(cfg, sd)(*(torch.from_numpy(z[k]) for k in ("price", "process", "gas")))
     assert np.array_equal(q32.numpy(), z["Q"])
