@@ -10,7 +10,6 @@
 namespace mctsq {
 
 constexpr int FF = 2048;
-constexpr int TOK_PER_WAVE = 64;
 constexpr int TOK_PER_WG = 256;
 
 // -------------------------------------------------------------------------------- embedding

@@ -40,7 +40,6 @@ __device__ __forceinline__ void gru3_head_tile(FusedLds& L, const GruFwdArgs& ga
     // the wave index (and everything derived from it: group, unit block, head tile) lives in scalar registers
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3, gtid = tid & 255;
-    const int jl = lane & 15, q = lane >> 4;
     const int64_t row0 = (int64_t)tile * (4 * RPL);
     GruLds& G = L.g[grp];
     // group 0 takes the longest window; group 1 runs the other two back to back on the same SIMDs (issue
