@@ -138,8 +138,9 @@ SPLIT3_BF16_CEILING = BF16_MATRIX_PEAK_TFLOPS / 6.0      # three-way bf16 split:
 
 def flop_classes(spec):
     """Forward FLOPs per leaf by the matrix instruction that EXECUTES them:
-    'fp16x3'  two-way fp16 split (GRU recurrence, the conv encoder's second convolution, the transformer FFN),
-    'bf16x6'  exact three-way bf16 split (attention in_proj / out_proj, the 192-128-128-A head),
+    'fp16x3'  two-way fp16 split (GRU recurrence, the conv encoder's second convolution, the transformer FFN and the
+              attention block's in_proj / out_proj),
+    'bf16x6'  exact three-way bf16 split (the 192-128-128-A head),
     'fp32'    v_mfma_f32_16x16x4_f32 and vector arithmetic (input projections, conv1, embedding, per-head attention,
               the gas/EUA MLP, pooling)."""
     c = {"fp16x3": 0, "bf16x6": 0, "fp32": 0}
@@ -153,8 +154,7 @@ def flop_classes(spec):
         elif kind == "mlp":
             c["fp32"] += 2 * 64 * 3 * F + 2 * 64 * 64
         elif kind == "transformer":
-            c["fp16x3"] += S * 2 * (4 * 64 * 2048)
-            c["bf16x6"] += S * 2 * (2 * 192 * 64 + 2 * 64 * 64)
+            c["fp16x3"] += S * 2 * (4 * 64 * 2048) + S * 2 * (2 * 192 * 64 + 2 * 64 * 64)
             c["fp32"] += S * (2 * 64 * F + 2 * 4 * S * 64)
     enc, head = forward_flops(spec)
     assert sum(c.values()) == enc

@@ -97,6 +97,9 @@ struct TfFfnTables {
     float b1s[FF], rs[FF], inv2[E];
     int s1[FF], s2[E];
     int kh, ku, pad_[2];
+    // attention block (tf_prepare_kernel): rows of in_proj / out_proj are scaled by powers of two into the fp16 range;
+    // 2^-shift per output column undoes it behind the accumulation
+    float inv_in[G3], inv_out[E];
 };
 static_assert(FFN_TABLES_OFF * 16 + (int64_t)sizeof(TfFfnTables) <= TF_FFN_PREP_BYTES, "scale tables fit behind the fragments");
 // ReLU as ONE integer maximum: a float with the sign bit set is a negative integer (fmaxf costs a second
@@ -130,52 +133,76 @@ __device__ __forceinline__ void tf_attn_body(float (&qkv)[AROWS * QLD], const Tf
     const int rows = ns * S;
     const int64_t tok0 = sample0 * S;
 
-    // ---- in_proj: [64 x 64] . W_in^T [64 x 192].  Split-bf16 product (six cross terms, fp32 accumulate) from
-    // prepared weight fragments.  Wave w OWNS COLUMN TILES w, w + 4, w + 8 for all four row tiles, so it fetches a
-    // quarter of the weight fragments (18 of 72 KB: with a wave per row tile every wave pulled all 72 KB through
-    // the CU's vector memory path, 384 KB per workgroup of 64 tokens, which bounded the phase).  The 64 h rows are
-    // split once -- wave w its own row tile -- and exchanged as lane-major fragments through the (not yet used)
-    // q|k|v region of LDS; every wave then keeps all four row tiles' A fragments in registers.
+    // ---- in_proj: [64 x 64] . W_in^T [64 x 192] on the two-way fp16 split (three cross terms, fp32 accumulate) from
+    // prepared weight fragments whose rows carry a power-of-two scale each (tf_prepare_kernel); the h rows are scaled
+    // per ROW TILE by the power of two that brings the tile's largest magnitude to the top of the fp16 range, found
+    // by the wave that splits the tile (a wave-local maximum: no extra rendezvous) and passed on with the fragments.
+    // Wave w OWNS COLUMN TILES w, w + 4, w + 8 for all four row tiles, so it fetches a quarter of the weight fragments
+    // (12 of 48 KB: with a wave per row tile every wave pulled all of them through the CU's vector memory path, which
+    // bounded the phase).  The 64 h rows are split once -- wave w its own row tile -- and exchanged as lane-major
+    // fragments through the (not yet used) q|k|v region of LDS; every wave then keeps all four row tiles' A fragments
+    // in registers.
     const u32x4* aprep = reinterpret_cast<const u32x4*>(a.ffn_prep[layer]) + (int64_t)FFN_PAIRS * FFN_REGION + lane;
+    const TfFfnTables& atb = *reinterpret_cast<const TfFfnTables*>(reinterpret_cast<const u32x4*>(a.ffn_prep[layer]) + FFN_TABLES_OFF);
     {
-        u32x4* xa = reinterpret_cast<u32x4*>(qkv);                   // [row tile 4][chunk 2][plane 3][lane 64]: 24 KB
+        u32x4* xa = reinterpret_cast<u32x4*>(qkv);                   // [row tile 4][chunk 2][plane 2][lane 64]: 16 KB
+        float* xk = qkv + 16 * 64 * 4;                               // behind them: 2^-k of the four row tiles
         {
             const bool ok = 16 * w + jl < rows;
             const float4* p = reinterpret_cast<const float4*>(hin + (tok0 + (ok ? 16 * w + jl : 0)) * E + 8 * q);
+            const float4 z = make_float4(0, 0, 0, 0);
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? p[8 * (i >> 1) + (i & 1)] : z;
+            float m = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+            m = row16_max_dpp(m);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const int kx = f16_row_shift(m);
+            const float sx = pow2i(kx);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float4 z = make_float4(0, 0, 0, 0);
-                u32x4 h3, m3, l3;
-                split8(ok ? p[8 * c] : z, ok ? p[8 * c + 1] : z, h3, m3, l3);
-                u32x4* dst = xa + ((w * 2 + c) * 3) * 64 + lane;
-                dst[0] = h3; dst[64] = m3; dst[128] = l3;
+                float4 v0 = v[2 * c], v1 = v[2 * c + 1];
+                v0.x *= sx; v0.y *= sx; v0.z *= sx; v0.w *= sx; v1.x *= sx; v1.y *= sx; v1.z *= sx; v1.w *= sx;
+                u32x4 h2, l2;
+                split8h(v0, v1, h2, l2);
+                u32x4* dst = xa + ((w * 2 + c) * 2) * 64 + lane;
+                dst[0] = h2; dst[64] = l2;
             }
+            if (lane == 0) xk[w] = pow2i(-kx);
         }
         __syncthreads();
-        u32x4 xf[4][2][3];
+        u32x4 xf[4][2][2];
+        float ikx[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < 4; ++rt) {
+            ikx[rt] = xk[rt];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xf[rt][c][pl] = xa[((rt * 2 + c) * 3 + pl) * 64 + lane];
+                for (int pl = 0; pl < 2; ++pl) xf[rt][c][pl] = xa[((rt * 2 + c) * 2 + pl) * 64 + lane];
+        }
         __syncthreads();                                            // the fragments are in registers: q|k|v may be written
 #pragma unroll 1
         for (int jt = 0; jt < 3; ++jt) {
             const int nt = w + 4 * jt;
-            u32x4 wc[6];
+            u32x4 wc[4];
 #pragma unroll
-            for (int f = 0; f < 6; ++f) wc[f] = aprep[(nt * 6 + f) * 64];
+            for (int f = 0; f < 4; ++f) wc[f] = aprep[(nt * 4 + f) * 64];
             const float bias = W.inb[16 * nt + jl];
+            const float un = atb.inv_in[16 * nt + jl];
             const float sc = nt < 4 ? 0.25f : 1.0f;                  // q / sqrt(head_dim)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-                TF_MM6(acc0, xf[rt][0][0], xf[rt][0][1], xf[rt][0][2], wc[0], wc[1], wc[2])
-                TF_MM6(acc1, xf[rt][1][0], xf[rt][1][1], xf[rt][1][2], wc[3], wc[4], wc[5])
+                TF_MM3(acc0, xf[rt][0][0], xf[rt][0][1], wc[0], wc[1])
+                TF_MM3(acc1, xf[rt][1][0], xf[rt][1][1], wc[2], wc[3])
+                const float us = un * ikx[rt];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v0 = ((acc0[r] + acc1[r]) + bias) * sc;
+                    const float v0 = ((acc0[r] + acc1[r]) * us + bias) * sc;
                     const int r0 = 16 * rt + 4 * q + r;
                     qkv[r0 * QLD + 16 * nt + jl] = v0;
                     if (Bf.qkv && r0 < rows) Bf.qkv[(tok0 + r0) * G3 + 16 * nt + jl] = v0;
@@ -253,38 +280,54 @@ __device__ __forceinline__ void tf_attn_body(float (&qkv)[AROWS * QLD], const Tf
     // ---- out_proj + residual + LayerNorm1 --------------------------------------------------------
     {
         const int rbase = 16 * w;
-        // A operand: the context row rbase + jl, 8 consecutive columns per K chunk, split here
-        u32x4 xh[2], xm[2], xl[2];
+        // A operand: the context row rbase + jl, 8 consecutive columns per K chunk, scaled by the power of two of this
+        // wave's largest context magnitude (the wave multiplies its own row tile only) and split here
+        float4 cv[4];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4* p = reinterpret_cast<const float4*>(&qkv[(rbase + jl) * QLD + 32 * c + 8 * q]);
-            const float4 v0 = p[0], v1 = p[1];
-            split8(v0, v1, xh[c], xm[c], xl[c]);
+            cv[2 * c] = p[0]; cv[2 * c + 1] = p[1];
             if (Bf.ctx && rbase + jl < rows) {
                 float4* dst = reinterpret_cast<float4*>(Bf.ctx + (tok0 + rbase + jl) * E + 32 * c + 8 * q);
-                dst[0] = v0; dst[1] = v1;
+                dst[0] = p[0]; dst[1] = p[1];
             }
         }
-        const u32x4* oprep = aprep + 72 * 64;
-        u32x4 wn[6];
+        float m = 0.0f;
 #pragma unroll
-        for (int f = 0; f < 6; ++f) wn[f] = oprep[f * 64];
+        for (int i = 0; i < 4; ++i) m = fmaxf(m, fmaxf(fmaxf(fabsf(cv[i].x), fabsf(cv[i].y)), fmaxf(fabsf(cv[i].z), fabsf(cv[i].w))));
+        m = row16_max_dpp(m);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const int kc = f16_row_shift(m);
+        const float sxc = pow2i(kc), ikc = pow2i(-kc);
+        u32x4 xh[2], xl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float4 v0 = cv[2 * c], v1 = cv[2 * c + 1];
+            v0.x *= sxc; v0.y *= sxc; v0.z *= sxc; v0.w *= sxc; v1.x *= sxc; v1.y *= sxc; v1.z *= sxc; v1.w *= sxc;
+            split8h(v0, v1, xh[c], xl[c]);
+        }
+        const u32x4* oprep = aprep + 48 * 64;
+        u32x4 wn[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) wn[f] = oprep[f * 64];
         float x[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            u32x4 wc[6];
+            u32x4 wc[4];
 #pragma unroll
-            for (int f = 0; f < 6; ++f) wc[f] = wn[f];
+            for (int f = 0; f < 4; ++f) wc[f] = wn[f];
             if (c + 1 < 4) {
 #pragma unroll
-                for (int f = 0; f < 6; ++f) wn[f] = oprep[((c + 1) * 6 + f) * 64];
+                for (int f = 0; f < 4; ++f) wn[f] = oprep[((c + 1) * 4 + f) * 64];
             }
             f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            TF_MM6(acc0, xh[0], xm[0], xl[0], wc[0], wc[1], wc[2])
-            TF_MM6(acc1, xh[1], xm[1], xl[1], wc[3], wc[4], wc[5])
+            TF_MM3(acc0, xh[0], xl[0], wc[0], wc[1])
+            TF_MM3(acc1, xh[1], xl[1], wc[2], wc[3])
             const float bias = W.ob[16 * c + jl];
+            const float us = atb.inv_out[16 * c + jl] * ikc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[c][r] = ((acc0[r] + acc1[r]) + bias) + res[c][r];
+            for (int r = 0; r < 4; ++r) x[c][r] = ((acc0[r] + acc1[r]) * us + bias) + res[c][r];
         }
         ln_rows(x, W.n1w, W.n1b, jl, q, Bf.x1 ? Bf.x1 + (tok0 + rbase) * E : nullptr,
                 Bf.x1 ? Bf.st1 + (tok0 + rbase) * 2 : nullptr, rows - rbase);
@@ -775,7 +818,8 @@ __global__ __launch_bounds__(1024) void tf_scales_kernel(const float* __restrict
 
 // FFN weights -> split-fp16 fragments: one thread per (pair, fragment group, lane); fragment order as
 // read by tf_ffn_kernel: W1 [unit tile m 2][K chunk c 2][plane 2], then W2 [out tile n 4][plane 2]; rows scaled by
-// the powers of two tf_scales_kernel chose.  The attention block's projections stay split-bf16 (three planes).
+// the powers of two tf_scales_kernel chose.  The attention block's projections: two fp16 planes per row as well, the row's
+// power of two chosen here (inverse in TfFfnTables::inv_in / inv_out).
 __global__ __launch_bounds__(256) void tf_prepare_kernel(const float* __restrict__ l1w, const float* __restrict__ l2w,
                                                         const float* __restrict__ inw, const float* __restrict__ ow,
                                                         u32x4* __restrict__ out) {
@@ -785,12 +829,27 @@ __global__ __launch_bounds__(256) void tf_prepare_kernel(const float* __restrict
     if (gid >= FFN_PAIRS * 8 * 64) {                          // in_proj / out_proj: (column tile, K chunk) per 64 lanes
         const int g2 = (gid - FFN_PAIRS * 8 * 64) >> 6;       // 0..23 in_proj, 24..31 out_proj
         const float* w = g2 < 24 ? inw : ow;
-        const int g = g2 < 24 ? g2 : g2 - 24, tile = g >> 1, c = g & 1;
-        const float4* p = reinterpret_cast<const float4*>(w + (int64_t)(16 * tile + jl) * E + 32 * c + 8 * q);
-        u32x4 hi, mid, lo;
-        split8(p[0], p[1], hi, mid, lo);
+        const int g = g2 < 24 ? g2 : g2 - 24, tile = g >> 1, c = g & 1, row = 16 * tile + jl;
+        // the row's power of two: every thread of the row reads all 64 weights (256 B, 2048 threads in all)
+        const float4* rw = reinterpret_cast<const float4*>(w + (int64_t)row * E);
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i) {
+            const float4 v = rw[i];
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        const int sh = f16_row_shift(amax);
+        const float sc = pow2i(sh);
+        float4 v0 = rw[8 * c + 2 * q], v1 = rw[8 * c + 2 * q + 1];
+        v0.x *= sc; v0.y *= sc; v0.z *= sc; v0.w *= sc; v1.x *= sc; v1.y *= sc; v1.z *= sc; v1.w *= sc;
+        u32x4 hi, lo;
+        split8h(v0, v1, hi, lo);
         u32x4* o = out + (int64_t)FFN_PAIRS * FFN_REGION + lane;
-        o[(g2 * 3 + 0) * 64] = hi; o[(g2 * 3 + 1) * 64] = mid; o[(g2 * 3 + 2) * 64] = lo;
+        o[(g2 * 2 + 0) * 64] = hi; o[(g2 * 2 + 1) * 64] = lo;
+        if (c == 0 && q == 0) {
+            TfFfnTables* tbw = reinterpret_cast<TfFfnTables*>(out + FFN_TABLES_OFF);
+            if (g2 < 24) tbw->inv_in[row] = pow2i(-sh); else tbw->inv_out[row] = pow2i(-sh);
+        }
         return;
     }
     const TfFfnTables& tb = *reinterpret_cast<const TfFfnTables*>(out + FFN_TABLES_OFF);

@@ -125,7 +125,7 @@ struct TfArgs {
     float* feats;                        // [Bp][192]
     float* sv_mean;                      // training: [Bp][64] mean over time before the final LayerNorm
     float* sv_xe;                        // training: [Tp][8] embedded-input rows incl. time features
-    const void* ffn_prep[2];             // per layer: FFN (split-fp16 fragments + scale tables), then in_proj / out_proj as split-bf16 fragments (tf_prepare_kernel)
+    const void* ffn_prep[2];             // per layer: FFN (split-fp16 fragments + scale tables), then in_proj / out_proj as split-fp16 fragments (tf_prepare_kernel)
 };
 int64_t tf_padded_tokens(int64_t B, int S);
 int launch_tf_fwd(const TfArgs& a, hipStream_t st);
@@ -134,9 +134,10 @@ int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st);   // t
 // order tf_ffn_kernel consumes them: u32x4 [pair of hidden tiles 64][fragment 16][lane 64] (1 MB), then the scale
 // tables of the split (enc_tf.hip: TfFfnTables) inside the same area
 constexpr int64_t TF_FFN_PREP_BYTES = 64 * 24 * 64 * 16;
-// ... followed by the attention block's in_proj [192][64] and out_proj [64][64] as split-bf16 B fragments:
-// u32x4 [in_proj column tile 12][K chunk 2][plane 3][lane 64], then [out_proj tile 4][K chunk 2][plane 3][lane 64]
-constexpr int64_t TF_ATTN_PREP_BYTES = (12 + 4) * 2 * 3 * 64 * 16;
+// ... followed by the attention block's in_proj [192][64] and out_proj [64][64] as split-fp16 B fragments (rows scaled by
+// powers of two, inverses in the scale tables): u32x4 [in_proj column tile 12][K chunk 2][plane 2][lane 64], then
+// [out_proj tile 4][K chunk 2][plane 2][lane 64]
+constexpr int64_t TF_ATTN_PREP_BYTES = (12 + 4) * 2 * 2 * 64 * 16;
 constexpr int64_t TF_LAYER_PREP_BYTES = TF_FFN_PREP_BYTES + TF_ATTN_PREP_BYTES;
 int launch_tf_prepare(const TfLayerW& w, void* prep, hipStream_t st);   // reads inw, ow, l1w, l1b, l2w, n1w, n1b
 
