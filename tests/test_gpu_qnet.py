@@ -279,12 +279,15 @@ def test_conv_encoder_scales(case):
     assert err_hip <= 1e-5
 
 
-@pytest.mark.parametrize("case", ["rows", "norm", "bias", "tiny"])
+@pytest.mark.parametrize("case", ["rows", "norm", "bias", "tiny", "attn_rows", "attn_embed", "attn_tiny"])
 def test_transformer_ffn_weights_of_any_scale(case):
     """The feed-forward block runs on the fp16 matrix instruction over a two-way split; its power-of-two scales come
     from the weights (enc_tf.hip: tf_scales_kernel -- rows of linear1 / linear2, the LayerNorm1 bound of the input,
     the bound of the hidden units).  Rows of both matrices spread over 2^-20 .. 2^2, a LayerNorm1 with large scale and
-    shift, large hidden biases and an all-tiny block against the fp64 oracle."""
+    shift, large hidden biases and an all-tiny block against the fp64 oracle.
+    attn_*: the attention block's in_proj / out_proj run on the same split with a power of two per weight row
+    (tf_prepare_kernel) and per 16-row tile of activations (found in the kernel): rows of both projections spread over
+    2^-12 .. 2^2, an embedding 300 times larger (layer 0's input has no bound), and tiny projections."""
     from mcts_q_amd import NetSpec
     from mcts_q_amd.qnet import DeviceQNet
     z, cfg, sd = _load(os.path.join(GOLDEN, "qnet_transformer_transformer_gru_per_relu.npz"))
@@ -302,6 +305,14 @@ def test_transformer_ffn_weights_of_any_scale(case):
             sd[k] = (sd[k] * 200.0).astype(np.float32); n += 1
         elif case == "tiny" and k.endswith(("linear1.weight", "linear1.bias", "linear2.weight")):
             sd[k] *= np.float32(1e-9); n += 1
+        elif case == "attn_rows" and k.endswith(("in_proj_weight", "out_proj.weight")):
+            sd[k] *= (2.0 ** rng.randint(-12, 3, size=(sd[k].shape[0], 1))).astype(np.float32); n += 1
+        elif case == "attn_tiny" and k.endswith(("in_proj_weight", "out_proj.weight")):
+            sd[k] *= np.float32(1e-6); n += 1
+    if case == "attn_embed":
+        for k in sd:
+            if k.endswith(("embedding.weight", "embedding.bias")):
+                sd[k] = (sd[k] * 300.0).astype(np.float32); n += 1
     assert n >= 4
     B = 37
     g = torch.Generator().manual_seed(13)
