@@ -108,10 +108,6 @@ __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(
 // three cross terms of the split-fp16 product, smallest first
 #define TF_MM3(ACC, XH, XL, YH, YL) \
     ACC = mfma_h(XL, YH, ACC); ACC = mfma_h(XH, YL, ACC); ACC = mfma_h(XH, YH, ACC);
-// six cross terms of the split-bf16 product, smallest first
-#define TF_MM6(ACC, XH, XM, XL, YH, YM, YL)                                              \
-    ACC = mfma_bf(XL, YH, ACC); ACC = mfma_bf(XH, YL, ACC); ACC = mfma_bf(XM, YM, ACC);   \
-    ACC = mfma_bf(XM, YH, ACC); ACC = mfma_bf(XH, YM, ACC); ACC = mfma_bf(XH, YH, ACC);
 
 // ------------------------------------------------------------------------------ attention block
 // One workgroup = NS whole samples (NS*S <= 64 token rows), 4 waves, one 16-row tile each.
