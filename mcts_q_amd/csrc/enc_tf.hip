@@ -13,38 +13,50 @@ constexpr int FF = 2048;
 constexpr int TOK_PER_WG = 256;
 
 // -------------------------------------------------------------------------------- embedding
-// One workgroup = 16 tokens x 64 columns; a thread keeps its column of the embedding weights in registers and
-// walks 4 consecutive tokens (one division per thread, (sample, step) advanced incrementally).
+// One workgroup = 64 tokens x 64 columns; a thread keeps FOUR consecutive columns of the embedding weights in registers
+// and walks 4 consecutive tokens (one division per thread, (sample, step) advanced incrementally): every store is 16
+// bytes per lane, 1 KB per wave instruction (with one column per thread - 4-byte stores, 16 tokens per workgroup - the
+// 16384-leaf launch ran at 1.6-2.3 TB/s of stores).
+constexpr int EMB_TOK = 64;
+static_assert(TOK_PER_WG % EMB_TOK == 0, "token padding covers whole embedding workgroups");
 __device__ __forceinline__ void tf_embed_body(const TfArgs& a, int bid) {
-    const int c = threadIdx.x & 63;
-    const int64_t tok0 = (int64_t)bid * 16 + (threadIdx.x >> 6) * 4;           // < Tp (Tp / 16 blocks per encoder)
-    float w[MAX_F];
+    const int c4 = (threadIdx.x & 15) * 4;                                      // first of this thread's four columns
+    const int64_t tok0 = (int64_t)bid * EMB_TOK + (threadIdx.x >> 4) * 4;       // < Tp
+    float w[4][MAX_F];
 #pragma unroll
-    for (int f = 0; f < MAX_F; ++f) w[f] = f < a.F ? a.ew[c * a.F + f] : 0.0f;
-    const float bias = a.eb[c];
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int f = 0; f < MAX_F; ++f) w[j][f] = f < a.F ? a.ew[(c4 + j) * a.F + f] : 0.0f;
+    const float4 bias = make_float4(a.eb[c4], a.eb[c4 + 1], a.eb[c4 + 2], a.eb[c4 + 3]);   // parameters are 4-byte aligned only
     int64_t b = tok0 / a.S;
     int t = (int)(tok0 - b * a.S);
     const int64_t nvalid = a.Bvalid * a.S;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t tok = tok0 + u;
-        float v = 0.0f;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (tok < nvalid) {
             v = bias;
 #pragma unroll
             for (int f = 0; f < MAX_F; ++f) {
                 if (f < a.F) {
                     const float x = f < a.Fd ? a.x[tok * a.Fd + f] : time_feature(a.tf, t, f - a.Fd);
-                    v = fmaf(x, w[f], v);
-                    if (a.sv_xe && c == 0) a.sv_xe[tok * 8 + f] = x;
+                    v.x = fmaf(x, w[0][f], v.x); v.y = fmaf(x, w[1][f], v.y);
+                    v.z = fmaf(x, w[2][f], v.z); v.w = fmaf(x, w[3][f], v.w);
+                    if (a.sv_xe && c4 == 0) a.sv_xe[tok * 8 + f] = x;
                 }
             }
-            if (a.sv_xe && c >= a.F && c < 8) a.sv_xe[tok * 8 + c] = 0.0f;
-            v += a.pos[t * E + c];
-        } else if (a.sv_xe && c < 8) {
-            a.sv_xe[tok * 8 + c] = 0.0f;
+            if (a.sv_xe && c4 == 4) {                              // columns F .. 7 of the record are zero
+#pragma unroll
+                for (int f = 0; f < 8; ++f)
+                    if (f >= a.F) a.sv_xe[tok * 8 + f] = 0.0f;
+            }
+            const float* p = a.pos + t * E + c4;
+            v.x += p[0]; v.y += p[1]; v.z += p[2]; v.w += p[3];
+        } else if (a.sv_xe && c4 < 8) {
+            *reinterpret_cast<float4*>(a.sv_xe + tok * 8 + c4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        a.buf[0].hin[tok * E + c] = v;
+        *reinterpret_cast<float4*>(a.buf[0].hin + tok * E + c4) = v;
         if (++t == a.S) { t = 0; ++b; }
     }
 }
@@ -889,7 +901,7 @@ int launch_tf_fwd(const TfArgs& a, hipStream_t st) {
     MCTSQ_CHECK(a.Tp % TOK_PER_WG == 0 && a.Tp >= a.T && a.T == a.B * a.S, "transformer encoder: bad token padding");
     MCTSQ_CHECK(a.NS >= 1 && a.NS * a.S <= AROWS, "transformer encoder: samples per workgroup");
     MCTSQ_CHECK(a.ffn_prep[0] && a.ffn_prep[1], "transformer encoder needs prepared FFN weights");
-    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(tf_embed_kernel, dim3((unsigned)(a.Tp / EMB_TOK)), dim3(256), 0, st, a);
     const unsigned attn_grid = (unsigned)((a.B + a.NS - 1) / a.NS), ffn_grid = (unsigned)(a.Tp / FFN_TOK);
     for (int l = 0; l < 2; ++l) {
         hipLaunchKernelGGL(tf_attn_kernel, dim3(attn_grid), dim3(256), 0, st, a, l);
@@ -913,7 +925,7 @@ int launch_tf_fwd_pair(const TfArgs& a, const TfArgs& b, hipStream_t st) {
     if (a.B == 0) return 0;
     if (tf_check(a) || tf_check(b)) return -1;
     MCTSQ_CHECK(a.B == b.B, "transformer encoder pair: batch mismatch");
-    hipLaunchKernelGGL(tf_embed_pair_kernel, dim3((unsigned)(a.Tp / 16 + b.Tp / 16)), dim3(256), 0, st, a, b, (int)(a.Tp / 16));
+    hipLaunchKernelGGL(tf_embed_pair_kernel, dim3((unsigned)(a.Tp / EMB_TOK + b.Tp / EMB_TOK)), dim3(256), 0, st, a, b, (int)(a.Tp / EMB_TOK));
     const int na = (int)(a.Tp / FFN_TOK), nb = (int)(b.Tp / FFN_TOK);
     for (int l = 0; l < 2; ++l) {
         const int ga = (int)((a.B + a.NS - 1) / a.NS), gb = (int)((b.B + b.NS - 1) / b.NS);
